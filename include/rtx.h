@@ -1,0 +1,172 @@
+/*
+ * rtx.h -- C ABI of the MI355X trace-loop backend.
+ *
+ * The reference renderer has no plugin or FFI seam: Scene::render (src/Scene.cpp:185-229) builds
+ * the scene, then runs an OpenMP loop that calls the private members traceRay / sceneIntersect /
+ * calcLightning directly.  This interface is cut exactly where that loop begins: everything
+ * before it (materials, primitives, textures, camera) is handed over as plain arrays, everything
+ * inside it (src/Scene.cpp:214-224 and all it calls) happens behind rtx_render(), and what comes
+ * back is the pixel store of the reference's bitmap_image: W*H*3 bytes, row 0 on top, B,G,R order
+ * (include/bitmap_image.hpp:198-210).
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative RTX_E_* code; rtx_last_error() gives the text
+ *     of the last failure on the calling thread;
+ *   - all array arguments are caller-owned host memory, copied during the call;
+ *   - a context is driven by one host thread at a time;
+ *   - all floating point is IEEE binary32 without fused multiply-add on the paths whose results
+ *     reach a pixel, so that results track the reference's x86-64 build.
+ *
+ * The same header is implemented twice: raytracing_amd/csrc (HIP, gfx950 -- the product) and
+ * oracle/rtx_oracle.cpp (CPU restatement -- the parity checker; test infrastructure only).
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK 0
+#define RTX_E_INVALID (-1)  /* bad argument (null pointer, negative count, index out of range) */
+#define RTX_E_STATE (-2)    /* call order: render before commit, scene change after commit ...  */
+#define RTX_E_DEVICE (-3)   /* HIP runtime error, text in rtx_last_error()                      */
+#define RTX_E_NOMEM (-4)
+#define RTX_E_LIMIT (-5)    /* a documented maximum was exceeded                                */
+
+#define RTX_MAX_DEPTH 8     /* recursion depth the per-lane ray stack is sized for              */
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Camera of Scene::render (src/Scene.cpp:195-202, 217-220).
+ * dir = normalize(basis * (x, y, z) + (add_origin ? origin : 0)), ray origin = origin, with
+ * x = (col + 0.5) - W/2, y = -(row + 0.5) + H/2, z = -H / (2 * tan_half_fov).
+ * The reference adds the camera position to the un-normalised direction (src/Scene.cpp:220);
+ * add_origin = 1 keeps that behaviour.
+ * tan_half_fov is passed as a number, not derived from an angle behind the interface: the
+ * reference's `tan(fov / 2.0f)` (src/Scene.cpp:219) has a constant argument, which its compiler
+ * folds to the correctly rounded 0x1.279a74p-1, while glibc's tanf returns 0x1.279a76p-1 for the
+ * same input at run time -- one ulp that moves almost every primary direction. */
+typedef struct rtx_camera {
+    float origin[3];
+    float basis[9]; /* 3x3, column-major: basis[3*c + r] = M[c][r] as GLM stores it */
+    float tan_half_fov;
+    int add_origin;
+} rtx_camera;
+
+/* One frame, or the share of one frame a rank owns.  Rows row_first, row_first + row_step, ...
+ * below H are rendered and stored compactly: output row k is image row row_first + k*row_step.
+ * A whole frame is row_first = 0, row_step = 1. */
+typedef struct rtx_frame {
+    int width;
+    int height;
+    int depth;     /* recursion depth, the literal 4 at src/Scene.cpp:221 */
+    int row_first;
+    int row_step;
+} rtx_frame;
+
+/* Ray counts of the last render ("ray" = one sceneIntersect call, src/Scene.cpp:29).  Only filled
+ * when the context was rendered with statistics enabled (rtx_set_option RTX_OPT_STATS = 1), which
+ * costs one atomic per wavefront per counter. */
+typedef struct rtx_stats {
+    uint64_t primary_rays;   /* traceRay calls at full depth                    */
+    uint64_t secondary_rays; /* traceRay calls below it that reach sceneIntersect */
+    uint64_t shadow_rays;    /* sceneIntersect calls from calcLightning         */
+    uint64_t sky_lookups;    /* Sky::getColorAt calls                           */
+    uint64_t mesh_box_hits;  /* rays that passed the mesh bounding box          */
+    uint64_t bvh_node_tests; /* inner-node (two-box) tests                      */
+    uint64_t triangle_tests; /* Moller-Trumbore tests on mesh triangles         */
+    double kernel_ms;        /* device time of the trace kernel(s), HIP events  */
+} rtx_stats;
+
+enum rtx_option {
+    RTX_OPT_STATS = 1,        /* 0/1: count rays (slower)                                          */
+    RTX_OPT_PRUNE = 2,        /* 0/1 (default 1): skip children whose albedo weight is exactly 0;
+                                 the reference traces them and multiplies by 0 (src/Scene.cpp:95-105) */
+    RTX_OPT_FAR_CLIP = 3,     /* float bits: sceneIntersect's `minDist < 700` (src/Scene.cpp:57)   */
+    RTX_OPT_SURFACE_BIAS = 4  /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
+};
+
+const char *rtx_last_error(void);
+
+/* replaces: `Scene scene;` + the SceneObjects aggregate (include/SceneObjects.h:127-154) */
+int rtx_create(rtx_ctx **out, int device_id);
+void rtx_destroy(rtx_ctx *ctx);
+int rtx_set_option(rtx_ctx *ctx, int option, uint32_t value);
+
+/* replaces: Materials table (src/Material.cpp:7-17).  m9 = n x {refractive, albedo[0..3],
+ * diffuse r,g,b, specular exponent}.  Primitives refer to materials by index. */
+int rtx_set_materials(rtx_ctx *ctx, const float *m9, int n);
+/* replaces: Scene::loadLights (src/Scene.cpp:133-139).  xyzi = n x {x, y, z, intensity};
+ * lights are applied in array order (src/Scene.cpp:64). */
+int rtx_set_lights(rtx_ctx *ctx, const float *xyzi, int n);
+/* replaces: Scene::loadSpheres + SceneObjects::spheresIntersect (src/Scene.cpp:108-115,
+ * src/SceneObjects.cpp:15-26, 289-302) */
+int rtx_set_spheres(rtx_ctx *ctx, const float *cx, const float *cy, const float *cz, const float *r,
+                    const int *mat, int n);
+/* replaces: Scene::loadCubes + cubesIntersect (src/Scene.cpp:117-131, src/SceneObjects.cpp:75-174,
+ * 382-397).  Corners may be given in any order (Cube::load sorts them per axis). */
+int rtx_set_boxes(rtx_ctx *ctx, const float *corner_a_xyz, const float *corner_b_xyz, const int *mat,
+                  int n);
+/* replaces: Scene::loadTriangles + trianglesIntersect (src/Scene.cpp:141-149,
+ * src/SceneObjects.cpp:28-49, 304-317).  v9 = n x {v0, v1, v2}; tested linearly, single-sided. */
+int rtx_set_triangles(rtx_ctx *ctx, const float *v9, const int *mat, int n);
+/* replaces: Model + BoundingBox + modelsIntersect (src/SceneObjects.cpp:176-255, 350-380).
+ * verts = nv x {x,y,z} already scaled and offset; idx = nt x 3, zero-based.  The bounding box
+ * that gates the mesh is the min/max over ALL nv vertices -/+ 1e-4 (src/SceneObjects.cpp:241-243).
+ * The HIP backend builds an LBVH over the triangles on the GPU in rtx_commit(); the oracle builds
+ * the reference's 7x7x7 vertex-binned grid. */
+int rtx_set_mesh(rtx_ctx *ctx, const float *verts, int nv, const int *idx, int nt, int mat);
+/* replaces: Scene::loadIslands + Island + islandsIntersect (src/Scene.cpp:159-166,
+ * src/SceneObjects.cpp:273-287, 399-419; include/SceneObjects.h:101-113).
+ * cx_cz_a_b = n x {centre x, centre z, semi-axis along x, semi-axis along z}. */
+int rtx_set_islands(rtx_ctx *ctx, const float *cx_cz_a_b, int n, float plane_y, int mat,
+                    const float *light_rgb, const float *dark_rgb);
+/* replaces: the water plane and its texture (src/Scene.cpp:38-54, 235-249).  rgb = h x w x 3
+ * bytes as stb_image returns them.  w = 0 removes the plane (the reference always has it). */
+int rtx_set_water(rtx_ctx *ctx, const unsigned char *rgb, int w, int h, float plane_y, float scale,
+                  int mat);
+/* replaces: Sky (src/SceneObjects.cpp:421-445).  row_shift = the literal 100 at :443. */
+int rtx_set_envmap(rtx_ctx *ctx, const unsigned char *rgb, int w, int h, int row_shift);
+
+/* Uploads the scene and builds the acceleration structure.  The scene is frozen afterwards. */
+int rtx_commit(rtx_ctx *ctx);
+
+/* replaces: the pixel loop of Scene::render (src/Scene.cpp:214-224).
+ * bgr_out: host buffer of rtx_frame_rows(frame) * width * 3 bytes.  stats may be NULL. */
+int rtx_render(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, unsigned char *bgr_out,
+               rtx_stats *stats);
+/* Same, for callers that own device memory (a torch tensor, an RCCL send buffer): d_bgr_out is a
+ * device pointer on the context's GPU, hip_stream a hipStream_t (NULL = the context's own stream).
+ * The call only enqueues work; the caller synchronises the stream.  The oracle has no device and
+ * returns RTX_E_STATE. */
+int rtx_render_device(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, void *d_bgr_out,
+                      void *hip_stream);
+/* Ray counts and kernel time of the most recent render on this context (synchronises). */
+int rtx_get_stats(rtx_ctx *ctx, rtx_stats *stats);
+
+/* number of rows a frame description owns: ceil((height - row_first) / row_step) */
+int rtx_frame_rows(const rtx_frame *frame);
+
+/* Row-interleaved gather, second half (the first half is an all-gather of equal-sized rank
+ * buffers over RCCL): d_gathered holds n_ranks blocks of rows_per_rank * width * 3 bytes, block r
+ * being rank r's compact rows (row_first = r, row_step = n_ranks); writes the height x width x 3
+ * frame to d_frame.  No counterpart in the reference (single process). */
+int rtx_deinterleave_rows_device(rtx_ctx *ctx, const void *d_gathered, int n_ranks, int rows_per_rank,
+                                 int width, int height, void *d_frame, void *hip_stream);
+
+/* Traces caller-supplied rays through Scene::traceRay semantics (src/Scene.cpp:83-106) and
+ * returns float RGB per ray, un-clamped.  Used by the parity tests to probe single rays.
+ * orig/dir = n x 3, rgb_out = n x 3 (host memory). */
+int rtx_trace_rays(rtx_ctx *ctx, const float *orig, const float *dir, int n, int depth, float *rgb_out);
+
+/* Closest-hit query = Scene::sceneIntersect (src/Scene.cpp:29-58) on caller-supplied rays.
+ * out16 = n x {hit flag, hit xyz, N xyz, refractive, albedo[0..3], diffuse rgb, specular}. */
+int rtx_intersect_rays(rtx_ctx *ctx, const float *orig, const float *dir, int n, float *out16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */
