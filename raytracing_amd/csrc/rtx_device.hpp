@@ -1,0 +1,256 @@
+// Device-side scene layout and the per-ray routines of the trace loop (gfx950, wave64).
+//
+// Arithmetic policy.  Every value that can reach a pixel is computed in IEEE binary32 in the
+// reference's operation order with NO fused multiply-add (this translation unit is built with
+// -ffp-contract=off and the routines below never call fmaf), because the reference is an x86-64
+// SSE2 build and a contracted a*b+c differs from it in the last bit.  The only places that use
+// FMA on purpose are the BVH box tests, which decide what gets tested, never what a test returns.
+//
+// Reference citations are relative to the reference checkout (src/..., include/...).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx {
+
+#define RTX_DEV __device__ __forceinline__
+
+constexpr float kEps = 1.1920928955078125e-07f;   // std::numeric_limits<float>::epsilon()
+constexpr float kFltMax = 3.4028234663852886e+38f;
+constexpr float kFltMin = 1.1754943508222875e-38f;  // numeric_limits<float>::min()
+constexpr int kMaxDepth = 8;                        // RTX_MAX_DEPTH
+constexpr int kBvhStack = 48;                       // LBVH depth bound: 30 Morton bits + tie-break levels
+
+struct V3 {
+    float x, y, z;
+};
+RTX_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RTX_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RTX_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTX_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RTX_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RTX_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// GLM's dot: tmp = a*b; tmp.x + tmp.y + tmp.z (include/glm/detail/func_geometric.inl:48-55)
+RTX_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// func_geometric.inl:68-79
+RTX_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+// v * (1 / sqrt(dot(v, v))): func_geometric.inl:82-90, func_exponential.inl:44-50
+RTX_DEV V3 normalize(V3 v) { return v * (1.0f / __fsqrt_rn(dot(v, v))); }
+// I - N * dot(N, I) * 2: func_geometric.inl:104-110
+RTX_DEV V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0f; }
+RTX_DEV float distance(V3 p0, V3 p1) {
+    V3 d = p1 - p0;
+    return __fsqrt_rn(dot(d, d));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene as the kernels see it.  Everything is read-only during a render.  The struct is passed
+// by value as a kernel argument, so its scalars and pointers sit in SGPRs and every loop over the
+// analytic primitives reads them with scalar loads.
+// ---------------------------------------------------------------------------------------------
+struct Material {  // 9 floats, include/Material.h:8-18
+    float refractive, a0, a1, a2, a3, dr, dg, db, spec;
+};
+
+// BVH2 node, 64 bytes: both children's boxes live in the parent so one fetch decides two subtrees.
+// child >= 0: inner node index; child < 0: ~child is a triangle index.
+struct BvhNode {
+    float lminx, lminy, lminz, lmaxx;
+    float lmaxy, lmaxz, rminx, rminy;
+    float rminz, rmaxx, rmaxy, rmaxz;
+    int left, right, pad0, pad1;
+};
+
+struct DevScene {
+    // materials, lights
+    const Material *materials;
+    int n_materials;
+    const float4 *lights;  // xyz, intensity
+    int n_lights;
+    // spheres: xyz, radius; material index
+    const float4 *spheres;
+    const int *sphere_mat;
+    int n_spheres;
+    // loose triangles: v0, v1, v2 (9 floats each)
+    const float *tris;
+    const int *tri_mat;
+    int n_tris;
+    // boxes: lo xyz, hi xyz (6 floats each)
+    const float *boxes;
+    const int *box_mat;
+    int n_boxes;
+    // mesh: triangles as v0, e1 = v1 - v0, e2 = v2 - v0 in three float4 (w unused), BVH2 over them
+    const float4 *mesh_tris;
+    const BvhNode *bvh;
+    int n_mesh_tris;
+    int mesh_mat;
+    float mesh_lo[3], mesh_hi[3];  // the gate box: all vertices -/+ 1e-4
+    // islands
+    const float4 *islands;  // cx, cz, a, b
+    int n_islands;
+    int island_mat;
+    float island_y;
+    float light_green[3], dark_green[3];
+    // water
+    const unsigned char *water;
+    int water_w, water_h, water_mat;
+    float water_y, water_scale;
+    // sky
+    const unsigned char *sky;
+    int sky_w, sky_h, sky_shift;
+    // constants
+    float far_clip;  // 700, src/Scene.cpp:57
+    float fprec;     // 1e-3, include/Scene.h:23
+    int prune;       // skip children whose weight is exactly 0
+};
+
+struct Counters {  // one 64-bit slot each; see rtx_stats in rtx.h
+    unsigned long long primary, secondary, shadow, sky, box_hits, node_tests, tri_tests;
+};
+
+struct Hit {
+    V3 point, N;
+    Material m;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Primitive tests
+// ---------------------------------------------------------------------------------------------
+
+// Sphere::rayIntersect, src/SceneObjects.cpp:15-26
+RTX_DEV bool sphereHit(V3 center, float radius, V3 orig, V3 dir, float &dist) {
+    V3 diff = center - orig;
+    float t0 = dot(diff, dir);
+    float dSquared = dot(diff, diff) - t0 * t0;
+    float radius2 = radius * radius;
+    if (dSquared > radius2) return false;
+    float t1 = __fsqrt_rn(radius2 - dSquared);
+    dist = t0 > t1 + kEps ? t0 - t1 : t0 + t1;
+    return dist > kEps;
+}
+
+// Triangle::rayIntersect, src/SceneObjects.cpp:28-49, on precomputed edges (edge1 = v1 - v0 and
+// edge2 = v2 - v0 are the same float subtractions the reference performs per call).
+RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist) {
+    V3 pvec = cross(dir, edge2);
+    float det = dot(edge1, pvec);
+    if (det < kEps) return false;
+    V3 tvec = orig - v0;
+    float u = dot(tvec, pvec);
+    if (u < 0 || u > det) return false;
+    V3 qvec = cross(tvec, edge1);
+    float v = dot(dir, qvec);
+    if (v < 0 || u + v > det) return false;
+    dist = dot(edge2, qvec) * (1.0f / det);
+    return dist > kEps;
+}
+
+// glm::triangleNormal = normalize(cross(p1 - p2, p1 - p3)), include/glm/gtx/normal.inl:5-14.
+// With e1 = v1 - v0, e2 = v2 - v0: v0 - v1 = -e1 and v0 - v2 = -e2 exactly, and the products of
+// two negated factors equal the products of the factors, so cross(-e1, -e2) == cross(e1, e2)
+// bit for bit.
+RTX_DEV V3 triNormal(V3 edge1, V3 edge2) { return normalize(cross(edge1, edge2)); }
+
+// Cube::rayIntersect(orig, dir, nearDist, farDist), src/SceneObjects.cpp:101-139.  An origin
+// inside the box returns true WITHOUT writing nearDist (the caller's 0 stays: "hit at distance 0").
+RTX_DEV bool boxSlab(const float lo[3], const float hi[3], V3 orig, V3 dir, float &nearDist) {
+    if (orig.x >= lo[0] && orig.x <= hi[0] && orig.y >= lo[1] && orig.y <= hi[1] && orig.z >= lo[2] && orig.z <= hi[2])
+        return true;
+    float t_near = kFltMin;  // +1.17549435e-38, as written at :108
+    float t_far = kFltMax;
+    const float o[3] = {orig.x, orig.y, orig.z};
+    const float d[3] = {dir.x, dir.y, dir.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (fabsf(d[i]) >= kEps) {
+            float t1 = (lo[i] - o[i]) / d[i];
+            float t2 = (hi[i] - o[i]) / d[i];
+            if (t1 > t2) {
+                float t = t1;
+                t1 = t2;
+                t2 = t;
+            }
+            if (t1 > t_near) t_near = t1;
+            if (t2 < t_far) t_far = t2;
+            if (t_near > t_far) return false;
+            if (t_far < kEps) return false;
+        } else {
+            if (o[i] < lo[i] || o[i] > hi[i]) return false;
+        }
+    }
+    if (!(t_near <= t_far && t_far >= kEps)) return false;
+    nearDist = t_near;
+    return true;
+}
+
+// float -> int the way the reference's x86-64 build converts (cvttss2si): NaN and out-of-range
+// give INT_MIN.  The plain device conversion saturates instead.
+RTX_DEV int truncToInt(float v) {
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return (int)0x80000000;
+    return (int)v;
+}
+RTX_DEV int truncToIntD(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+// Normal of Cube::rayIntersect(orig, dir, dist, n), src/SceneObjects.cpp:146-172
+RTX_DEV V3 boxNormal(const float lo[3], const float hi[3], V3 hit) {
+    V3 c = (v3(lo[0], lo[1], lo[2]) + v3(hi[0], hi[1], hi[2])) * 0.5f;
+    V3 d = (v3(lo[0], lo[1], lo[2]) - v3(hi[0], hi[1], hi[2])) * 0.5f;
+    V3 p = hit - c;
+    const float bias = 1.000001f;
+    float v1 = p.x / fabsf(d.x) * bias;
+    float v2 = p.y / fabsf(d.y) * bias;
+    float v3_ = p.z / fabsf(d.z) * bias;
+    int iv1 = truncToInt(v1), iv2 = truncToInt(v2), iv3 = truncToInt(v3_);
+    if (iv1 == 0 && iv2 == 0 && iv3 == 0) {
+        float mx = v1 > v2 ? v1 : v2;
+        mx = mx > v3_ ? mx : v3_;
+        if (fabsf(v1 - mx) < kEps)
+            iv1 = 1;
+        else if (fabsf(v2 - mx) < kEps)
+            iv2 = 1;
+        else
+            iv3 = 1;
+    }
+    return normalize(v3((float)iv1, (float)iv2, (float)iv3));
+}
+
+// glm::intersectRayPlane for the plane y = plane_y with normal (0,1,0)
+// (include/glm/gtx/intersect.inl:6-26).  dot(dir, n) = dir.x*0 + dir.y*1 + dir.z*0 equals dir.y
+// and dot(p0 - orig, n) equals plane_y - orig.y whenever the other components are finite (adding
+// a signed zero changes nothing but the sign of a zero, which neither comparison below sees).
+RTX_DEV bool planeHit(float plane_y, V3 orig, V3 dir, float &dist) {
+    float d = dir.y;
+    if (fabsf(d) > kEps) {
+        float t = (plane_y - orig.y) / d;
+        if (t > 0.0f) {
+            dist = t;
+            return true;
+        }
+    }
+    return false;
+}
+
+// free refract(), src/Scene.cpp:19-27; the recursion there happens at most once (it flips N and
+// swaps the indices when the ray leaves the medium).
+RTX_DEV V3 refractDir(V3 I, V3 N, float etat) {
+    float etai = 1.0f;
+    float cosi = -fmaxf(-1.0f, fminf(1.0f, dot(I, N)));
+    if (cosi < 0) {
+        N = -N;
+        float t = etai;
+        etai = etat;
+        etat = t;
+        cosi = -fmaxf(-1.0f, fminf(1.0f, dot(I, N)));
+        // a second flip cannot make progress; the reference would recurse again only for
+        // cosi < 0 here, which needs dot(I,N) and dot(I,-N) both positive
+    }
+    float eta = etai / etat;
+    float k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) return v3(1, 0, 0);
+    return I * eta + N * (eta * cosi - __fsqrt_rn(k));
+}
+
+}  // namespace rtx

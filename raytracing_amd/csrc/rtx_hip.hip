@@ -1,0 +1,609 @@
+// HIP (gfx950) implementation of include/rtx.h: kernels, scene upload, C ABI.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see raytracing_amd/build.py).
+// -ffp-contract=off is part of the contract: the pixel arithmetic must not be fused (see
+// rtx_device.hpp).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "lbvh_build.hpp"
+#include "rtx_device.hpp"
+#include "rtx_trace.hpp"
+
+using namespace rtx;
+
+namespace {
+
+constexpr int kBlock = 256;     // 4 waves; a block renders a 16x16 pixel tile, a wave an 8x8 quadrant
+constexpr int kTile = 16;
+constexpr int kStackDepth = 32; // LDS traversal stack entries per lane (checked against the tree's depth)
+
+struct DevCamera {
+    float ox, oy, oz;
+    float m[9];
+    float tan_half_fov;
+    int add_origin;
+};
+
+struct DevFrame {
+    int width, height, depth, row_first, row_step, rows;
+};
+
+// src/Scene.cpp:217-220
+RTX_DEV V3 primaryDir(const DevCamera &cam, int width, int height, int i, int j) {
+    float x = ((float)j + 0.5f) - (float)width / 2.0f;
+    float y = -((float)i + 0.5f) + (float)height / 2.0f;
+    float z = (float)(-height) / (2.0f * cam.tan_half_fov);
+    // mat3 * vec3: include/glm/detail/type_mat3x3.inl:468-474
+    V3 d = v3(cam.m[0] * x + cam.m[3] * y + cam.m[6] * z, cam.m[1] * x + cam.m[4] * y + cam.m[7] * z,
+              cam.m[2] * x + cam.m[5] * y + cam.m[8] * z);
+    if (cam.add_origin) d = d + v3(cam.ox, cam.oy, cam.oz);
+    return normalize(d);
+}
+
+// getRGBColor, src/Scene.cpp:204-210: 255 * clamp(c, 0, 1), truncated
+RTX_DEV unsigned char toByte(float c) { return (unsigned char)(255 * fmaxf(0.0f, fminf(1.0f, c))); }
+
+template <bool STATS>
+RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
+    if constexpr (STATS) {
+        unsigned v[7] = {lc.primary, lc.secondary, lc.shadow, lc.sky, lc.box_hits, lc.node_tests, lc.tri_tests};
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&o[k], x);
+        }
+    }
+}
+
+// One lane per pixel.  Block b renders tile (b % tiles_x, b / tiles_x) of the rank's compact
+// image (rows row_first, row_first + row_step, ...); wave w takes the 8x8 quadrant (w & 1, w >> 1)
+// so that the 64 rays of a wave stay close together.
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, int tiles_x,
+                                                   unsigned char *__restrict__ out, Counters *counters) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = tile_x * kTile + (wave & 1) * 8 + (lane & 7);
+    const int pk = tile_y * kTile + (wave >> 1) * 8 + (lane >> 3);
+    LaneCounters<STATS> lc;
+    if (px < fr.width && pk < fr.rows) {
+        const int row = fr.row_first + pk * fr.row_step;
+        const V3 dir = primaryDir(cam, fr.width, fr.height, row, px);
+        const V3 c = traceRay<STATS>(s, v3(cam.ox, cam.oy, cam.oz), dir, fr.depth, s_stack + threadIdx.x, kBlock, lc);
+        unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
+        p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
+    }
+    flushCounters<STATS>(lc, counters);
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *__restrict__ orig,
+                                                       const float *__restrict__ dir, int n, int depth,
+                                                       float *__restrict__ rgb) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    LaneCounters<false> lc;
+    const V3 c = traceRay<false>(s, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+                                 v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, s_stack + threadIdx.x, kBlock, lc);
+    rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+}
+
+__global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const float *__restrict__ orig,
+                                                           const float *__restrict__ dir, int n,
+                                                           float *__restrict__ out16) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    LaneCounters<false> lc;
+    Hit h;
+    h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
+    h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
+    float md;
+    const bool ok = sceneIntersect<false, false>(s, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+                                                 v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), h, md, 0.0f,
+                                                 s_stack + threadIdx.x, kBlock, lc);
+    float *o = out16 + 16 * (size_t)i;
+    o[0] = ok ? 1.0f : 0.0f;
+    o[1] = h.point.x, o[2] = h.point.y, o[3] = h.point.z;
+    o[4] = h.N.x, o[5] = h.N.y, o[6] = h.N.z;
+    o[7] = h.m.refractive, o[8] = h.m.a0, o[9] = h.m.a1, o[10] = h.m.a2, o[11] = h.m.a3;
+    o[12] = h.m.dr, o[13] = h.m.dg, o[14] = h.m.db, o[15] = h.m.spec;
+}
+
+// gathered: n_ranks blocks of rows_per_rank rows; block r row k is image row r + k * n_ranks
+__global__ void k_deinterleave(const unsigned char *__restrict__ gathered, int n_ranks, int rows_per_rank,
+                               int row_bytes, int height, unsigned char *__restrict__ frame) {
+    const size_t total = (size_t)height * row_bytes;
+    if ((row_bytes & 3) == 0) {
+        const size_t n4 = total >> 2;
+        const int row4 = row_bytes >> 2;
+        for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+            const int i = (int)(t / row4), c = (int)(t % row4);
+            const int r = i % n_ranks, k = i / n_ranks;
+            reinterpret_cast<unsigned *>(frame)[t] =
+                reinterpret_cast<const unsigned *>(gathered)[((size_t)r * rows_per_rank + k) * row4 + c];
+        }
+    } else {
+        for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+            const int i = (int)(t / row_bytes), c = (int)(t % row_bytes);
+            const int r = i % n_ranks, k = i / n_ranks;
+            frame[t] = gathered[((size_t)r * rows_per_rank + k) * row_bytes + c];
+        }
+    }
+}
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int failHip(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return RTX_E_DEVICE;
+}
+
+#define HIP_OR_FAIL(expr)                                  \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return failHip(e_, #expr);   \
+    } while (0)
+
+template <typename T>
+int upload(const std::vector<T> &v, T **dptr, std::vector<void *> &owned) {
+    *dptr = nullptr;
+    if (v.empty()) return RTX_OK;
+    void *p = nullptr;
+    HIP_OR_FAIL(hipMalloc(&p, v.size() * sizeof(T)));
+    owned.push_back(p);
+    HIP_OR_FAIL(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = static_cast<T *>(p);
+    return RTX_OK;
+}
+
+}  // namespace
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // host staging (until commit)
+    std::vector<Material> materials;
+    std::vector<float4> lights;
+    std::vector<float4> spheres;
+    std::vector<int> sphere_mat;
+    std::vector<float> tris;
+    std::vector<int> tri_mat;
+    std::vector<float> boxes;
+    std::vector<int> box_mat;
+    std::vector<float> mesh_verts;
+    std::vector<int> mesh_idx;
+    int mesh_mat = 0;
+    std::vector<float4> islands;
+    float island_y = -4.0f;
+    int island_mat = 0;
+    float light_green[3] = {0, 0, 0}, dark_green[3] = {0, 0, 0};
+    std::vector<unsigned char> water;
+    int water_w = 0, water_h = 0, water_mat = 0;
+    float water_y = -4.5f, water_scale = 10.0f;
+    std::vector<unsigned char> sky;
+    int sky_w = 0, sky_h = 0, sky_shift = 100;
+    // options
+    bool stats = false;
+    int prune = 1;
+    float far_clip = 700.0f, fprec = 0.001f;
+    // device state
+    bool committed = false;
+    DevScene dev{};
+    std::vector<void *> owned;
+    int bvh_depth = 0;
+    Counters *d_counters = nullptr;
+    unsigned char *d_frame = nullptr;
+    size_t d_frame_bytes = 0;
+};
+
+namespace {
+
+int bind(rtx_ctx *c) {
+    HIP_OR_FAIL(hipSetDevice(c->device));
+    return RTX_OK;
+}
+
+int checkMat(const rtx_ctx *c, const int *mat, int n) {
+    for (int i = 0; i < n; ++i)
+        if (mat[i] < 0 || (size_t)mat[i] >= c->materials.size()) return fail(RTX_E_INVALID, "material index out of range");
+    return RTX_OK;
+}
+
+int checkFrame(const rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f) {
+    if (!c || !cam || !f) return fail(RTX_E_INVALID, "null argument");
+    if (!c->committed) return fail(RTX_E_STATE, "render before rtx_commit");
+    if (f->width <= 0 || f->height <= 0 || f->row_step <= 0 || f->row_first < 0)
+        return fail(RTX_E_INVALID, "bad frame description");
+    if (f->depth < 0 || f->depth > RTX_MAX_DEPTH) return fail(RTX_E_LIMIT, "depth outside [0, RTX_MAX_DEPTH]");
+    return RTX_OK;
+}
+
+DevCamera devCamera(const rtx_camera *cam) {
+    DevCamera d;
+    d.ox = cam->origin[0], d.oy = cam->origin[1], d.oz = cam->origin[2];
+    for (int k = 0; k < 9; ++k) d.m[k] = cam->basis[k];
+    d.tan_half_fov = cam->tan_half_fov;
+    d.add_origin = cam->add_origin;
+    return d;
+}
+
+// enqueue one render on `stream`; output rows * width * 3 bytes at d_out
+int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
+    const int rows = rtx_frame_rows(f);
+    if (rows == 0) return RTX_OK;
+    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows};
+    const int tiles_x = (f->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
+    const long long blocks = (long long)tiles_x * tiles_y;
+    if (blocks > 0x7fffffffLL) return fail(RTX_E_LIMIT, "frame too large for one launch");
+    DevScene s = c->dev;
+    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
+    HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
+    if (c->stats)
+        hipLaunchKernelGGL(k_render<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, tiles_x, d_out, c->d_counters);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, tiles_x, d_out, c->d_counters);
+    HIP_OR_FAIL(hipGetLastError());
+    HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtx_last_error(void) { return g_err.c_str(); }
+
+int rtx_create(rtx_ctx **out, int device_id) {
+    if (!out) return fail(RTX_E_INVALID, "rtx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(RTX_E_DEVICE, std::string("rtx_create: no HIP device available (") +
+                                      (e != hipSuccess ? hipGetErrorString(e) : "0 devices") + ")");
+    if (device_id < 0 || device_id >= n) return fail(RTX_E_INVALID, "rtx_create: device id out of range");
+    rtx_ctx *c = new rtx_ctx();
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess) {
+        delete c;
+        return failHip(e, "rtx_create");
+    }
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->owned) (void)hipFree(p);
+    (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_frame);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
+    if (!c) return fail(RTX_E_INVALID, "null context");
+    float f;
+    memcpy(&f, &value, 4);
+    switch (option) {
+        case RTX_OPT_STATS: c->stats = value != 0; break;
+        case RTX_OPT_PRUNE: c->prune = value != 0; break;
+        case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
+        case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
+        default: return fail(RTX_E_INVALID, "unknown option");
+    }
+    return RTX_OK;
+}
+
+#define NEED(c)                                           \
+    if (!(c)) return fail(RTX_E_INVALID, "null context"); \
+    if ((c)->committed) return fail(RTX_E_STATE, "scene is frozen after rtx_commit")
+
+int rtx_set_materials(rtx_ctx *c, const float *m9, int n) {
+    NEED(c);
+    if (n < 0 || (n > 0 && !m9)) return fail(RTX_E_INVALID, "rtx_set_materials: bad arguments");
+    c->materials.resize(n);
+    static_assert(sizeof(Material) == 9 * sizeof(float), "Material must be 9 packed floats");
+    if (n) memcpy(c->materials.data(), m9, sizeof(Material) * (size_t)n);
+    return RTX_OK;
+}
+
+int rtx_set_lights(rtx_ctx *c, const float *xyzi, int n) {
+    NEED(c);
+    if (n < 0 || (n > 0 && !xyzi)) return fail(RTX_E_INVALID, "rtx_set_lights: bad arguments");
+    c->lights.resize(n);
+    for (int i = 0; i < n; ++i) c->lights[i] = make_float4(xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2], xyzi[4 * i + 3]);
+    return RTX_OK;
+}
+
+int rtx_set_spheres(rtx_ctx *c, const float *cx, const float *cy, const float *cz, const float *r, const int *mat, int n) {
+    NEED(c);
+    if (n < 0 || (n > 0 && (!cx || !cy || !cz || !r || !mat))) return fail(RTX_E_INVALID, "rtx_set_spheres: bad arguments");
+    if (int e = checkMat(c, mat, n)) return e;
+    c->spheres.resize(n);
+    for (int i = 0; i < n; ++i) c->spheres[i] = make_float4(cx[i], cy[i], cz[i], r[i]);
+    c->sphere_mat.assign(mat, mat + n);
+    return RTX_OK;
+}
+
+int rtx_set_boxes(rtx_ctx *c, const float *a, const float *b, const int *mat, int n) {
+    NEED(c);
+    if (n < 0 || (n > 0 && (!a || !b || !mat))) return fail(RTX_E_INVALID, "rtx_set_boxes: bad arguments");
+    if (int e = checkMat(c, mat, n)) return e;
+    c->boxes.resize(6 * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {  // Cube::load, src/SceneObjects.cpp:75-89
+            const float p = a[3 * i + k], q = b[3 * i + k];
+            c->boxes[6 * i + k] = p < q ? p : q;      // std::min(minP, maxP)
+            c->boxes[6 * i + 3 + k] = p < q ? q : p;  // std::max(minP, maxP)
+        }
+    c->box_mat.assign(mat, mat + n);
+    return RTX_OK;
+}
+
+int rtx_set_triangles(rtx_ctx *c, const float *v9, const int *mat, int n) {
+    NEED(c);
+    if (n < 0 || (n > 0 && (!v9 || !mat))) return fail(RTX_E_INVALID, "rtx_set_triangles: bad arguments");
+    if (int e = checkMat(c, mat, n)) return e;
+    c->tris.assign(v9, v9 + 9 * (size_t)n);
+    c->tri_mat.assign(mat, mat + n);
+    return RTX_OK;
+}
+
+int rtx_set_mesh(rtx_ctx *c, const float *verts, int nv, const int *idx, int nt, int mat) {
+    NEED(c);
+    if (nv < 0 || nt < 0 || (nv > 0 && !verts) || (nt > 0 && !idx)) return fail(RTX_E_INVALID, "rtx_set_mesh: bad arguments");
+    if (nt > 0)
+        if (int e = checkMat(c, &mat, 1)) return e;
+    for (int i = 0; i < 3 * nt; ++i)
+        if (idx[i] < 0 || idx[i] >= nv) return fail(RTX_E_INVALID, "rtx_set_mesh: vertex index out of range");
+    c->mesh_verts.assign(verts, verts + 3 * (size_t)nv);
+    c->mesh_idx.assign(idx, idx + 3 * (size_t)nt);
+    c->mesh_mat = mat;
+    return RTX_OK;
+}
+
+int rtx_set_islands(rtx_ctx *c, const float *p, int n, float plane_y, int mat, const float *light_rgb, const float *dark_rgb) {
+    NEED(c);
+    if (n < 0 || (n > 0 && (!p || !light_rgb || !dark_rgb))) return fail(RTX_E_INVALID, "rtx_set_islands: bad arguments");
+    if (n > 0)
+        if (int e = checkMat(c, &mat, 1)) return e;
+    c->islands.resize(n);
+    for (int i = 0; i < n; ++i) c->islands[i] = make_float4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+    c->island_y = plane_y, c->island_mat = mat;
+    if (n > 0)
+        for (int k = 0; k < 3; ++k) c->light_green[k] = light_rgb[k], c->dark_green[k] = dark_rgb[k];
+    return RTX_OK;
+}
+
+int rtx_set_water(rtx_ctx *c, const unsigned char *rgb, int w, int h, float plane_y, float scale, int mat) {
+    NEED(c);
+    if (w < 0 || h < 0 || ((w > 0 || h > 0) && (!rgb || w == 0 || h == 0))) return fail(RTX_E_INVALID, "rtx_set_water: bad arguments");
+    if (w > 0)
+        if (int e = checkMat(c, &mat, 1)) return e;
+    c->water_w = w, c->water_h = h, c->water_y = plane_y, c->water_scale = scale, c->water_mat = mat;
+    c->water.assign(rgb, rgb + (size_t)w * h * 3);
+    return RTX_OK;
+}
+
+int rtx_set_envmap(rtx_ctx *c, const unsigned char *rgb, int w, int h, int row_shift) {
+    NEED(c);
+    if (w <= 0 || h <= 0 || !rgb) return fail(RTX_E_INVALID, "rtx_set_envmap: bad arguments");
+    c->sky_w = w, c->sky_h = h, c->sky_shift = row_shift;
+    c->sky.assign(rgb, rgb + (size_t)w * h * 3);
+    return RTX_OK;
+}
+
+int rtx_commit(rtx_ctx *c) {
+    if (!c) return fail(RTX_E_INVALID, "null context");
+    if (c->committed) return fail(RTX_E_STATE, "already committed");
+    if (c->sky_w == 0) return fail(RTX_E_STATE, "rtx_commit: no environment map (the reference cannot render without one)");
+    if (c->materials.empty()) return fail(RTX_E_STATE, "rtx_commit: no materials");
+    if (int e = bind(c)) return e;
+    DevScene &d = c->dev;
+    memset(&d, 0, sizeof d);
+    Material *dm;
+    float4 *dl, *dsp, *dis;
+    int *dsm, *dtm, *dbm;
+    float *dt, *db;
+    unsigned char *dw, *dsk;
+    if (int e = upload(c->materials, &dm, c->owned)) return e;
+    if (int e = upload(c->lights, &dl, c->owned)) return e;
+    if (int e = upload(c->spheres, &dsp, c->owned)) return e;
+    if (int e = upload(c->sphere_mat, &dsm, c->owned)) return e;
+    if (int e = upload(c->tris, &dt, c->owned)) return e;
+    if (int e = upload(c->tri_mat, &dtm, c->owned)) return e;
+    if (int e = upload(c->boxes, &db, c->owned)) return e;
+    if (int e = upload(c->box_mat, &dbm, c->owned)) return e;
+    if (int e = upload(c->islands, &dis, c->owned)) return e;
+    if (int e = upload(c->water, &dw, c->owned)) return e;
+    if (int e = upload(c->sky, &dsk, c->owned)) return e;
+    d.materials = dm, d.n_materials = (int)c->materials.size();
+    d.lights = dl, d.n_lights = (int)c->lights.size();
+    d.spheres = dsp, d.sphere_mat = dsm, d.n_spheres = (int)c->spheres.size();
+    d.tris = dt, d.tri_mat = dtm, d.n_tris = (int)c->tri_mat.size();
+    d.boxes = db, d.box_mat = dbm, d.n_boxes = (int)c->box_mat.size();
+    d.islands = dis, d.n_islands = (int)c->islands.size(), d.island_mat = c->island_mat, d.island_y = c->island_y;
+    for (int k = 0; k < 3; ++k) d.light_green[k] = c->light_green[k], d.dark_green[k] = c->dark_green[k];
+    d.water = dw, d.water_w = c->water_w, d.water_h = c->water_h, d.water_mat = c->water_mat;
+    d.water_y = c->water_y, d.water_scale = c->water_scale;
+    d.sky = dsk, d.sky_w = c->sky_w, d.sky_h = c->sky_h, d.sky_shift = c->sky_shift;
+
+    const int nt = (int)(c->mesh_idx.size() / 3), nv = (int)(c->mesh_verts.size() / 3);
+    d.n_mesh_tris = 0;
+    if (nt > 0) {
+        // gate box: min/max over all vertices -/+ 1e-4, src/SceneObjects.cpp:222-243
+        float lo[3] = {1000, 1000, 1000}, hi[3] = {-1000, -1000, -1000};
+        for (int i = 0; i < nv; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float v = c->mesh_verts[3 * i + k];
+                lo[k] = v < lo[k] ? v : lo[k];  // std::min(min_x, v.x)
+                hi[k] = hi[k] < v ? v : hi[k];  // std::max(max_x, v.x)
+            }
+        const float eps = 0.0001f;
+        for (int k = 0; k < 3; ++k) {
+            const float a = lo[k] - eps, b = hi[k] + eps;
+            d.mesh_lo[k] = a < b ? a : b, d.mesh_hi[k] = a < b ? b : a;  // Cube::load
+        }
+        float *dv;
+        int *di;
+        if (int e = upload(c->mesh_verts, &dv, c->owned)) return e;
+        if (int e = upload(c->mesh_idx, &di, c->owned)) return e;
+        LbvhResult r;
+        hipError_t he = lbvhBuild(dv, di, nt, c->stream, &r);
+        if (he != hipSuccess) return failHip(he, "LBVH build");
+        c->owned.push_back(r.tris), c->owned.push_back(r.nodes);
+        if (r.max_depth > kStackDepth) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "LBVH depth %d exceeds the traversal stack (%d entries)", r.max_depth, kStackDepth);
+            return fail(RTX_E_LIMIT, msg);
+        }
+        c->bvh_depth = r.max_depth;
+        d.mesh_tris = r.tris, d.bvh = r.nodes, d.n_mesh_tris = nt, d.mesh_mat = c->mesh_mat;
+    }
+    c->committed = true;
+    // host copies are no longer needed
+    std::vector<unsigned char>().swap(c->sky);
+    std::vector<unsigned char>().swap(c->water);
+    return RTX_OK;
+}
+
+int rtx_frame_rows(const rtx_frame *f) {
+    if (!f || f->row_step <= 0 || f->row_first < 0 || f->row_first >= f->height) return 0;
+    return (f->height - f->row_first + f->row_step - 1) / f->row_step;
+}
+
+int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *bgr_out, rtx_stats *stats) {
+    if (int e = checkFrame(c, cam, f)) return e;
+    const int rows = rtx_frame_rows(f);
+    if (rows > 0 && !bgr_out) return fail(RTX_E_INVALID, "null output buffer");
+    if (int e = bind(c)) return e;
+    const size_t bytes = (size_t)rows * f->width * 3;
+    if (bytes > c->d_frame_bytes) {
+        (void)hipFree(c->d_frame);
+        c->d_frame = nullptr, c->d_frame_bytes = 0;
+        HIP_OR_FAIL(hipMalloc((void **)&c->d_frame, bytes));
+        c->d_frame_bytes = bytes;
+    }
+    if (int e = launchRender(c, cam, f, c->d_frame, c->stream)) return e;
+    if (bytes) HIP_OR_FAIL(hipMemcpyAsync(bgr_out, c->d_frame, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_OR_FAIL(hipStreamSynchronize(c->stream));
+    if (stats) return rtx_get_stats(c, stats);
+    return RTX_OK;
+}
+
+int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, void *d_bgr_out, void *hip_stream) {
+    if (int e = checkFrame(c, cam, f)) return e;
+    if (rtx_frame_rows(f) > 0 && !d_bgr_out) return fail(RTX_E_INVALID, "null output buffer");
+    if (int e = bind(c)) return e;
+    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream);
+}
+
+int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {
+    if (!c || !o) return fail(RTX_E_INVALID, "null argument");
+    memset(o, 0, sizeof *o);
+    if (!c->timed) return RTX_OK;
+    if (int e = bind(c)) return e;
+    HIP_OR_FAIL(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_OR_FAIL(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    o->kernel_ms = ms;
+    if (c->stats) {
+        Counters h;
+        HIP_OR_FAIL(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+        o->primary_rays = h.primary, o->secondary_rays = h.secondary, o->shadow_rays = h.shadow, o->sky_lookups = h.sky;
+        o->mesh_box_hits = h.box_hits, o->bvh_node_tests = h.node_tests, o->triangle_tests = h.tri_tests;
+    }
+    return RTX_OK;
+}
+
+int rtx_deinterleave_rows_device(rtx_ctx *c, const void *d_gathered, int n_ranks, int rows_per_rank, int width,
+                                 int height, void *d_frame, void *hip_stream) {
+    if (!c || !d_gathered || !d_frame) return fail(RTX_E_INVALID, "null argument");
+    if (n_ranks <= 0 || rows_per_rank <= 0 || width <= 0 || height <= 0) return fail(RTX_E_INVALID, "bad sizes");
+    if ((long long)rows_per_rank * n_ranks < height) return fail(RTX_E_INVALID, "gathered buffer holds fewer rows than the frame");
+    if (int e = bind(c)) return e;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    const size_t total = (size_t)height * width * 3;
+    const unsigned grid = (unsigned)std::min<size_t>((total / 4 + 255) / 256 + 1, 256 * 8);
+    hipLaunchKernelGGL(k_deinterleave, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char *>(d_gathered), n_ranks,
+                       rows_per_rank, width * 3, height, static_cast<unsigned char *>(d_frame));
+    HIP_OR_FAIL(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_trace_rays(rtx_ctx *c, const float *orig, const float *dir, int n, int depth, float *rgb_out) {
+    if (!c || n < 0 || (n > 0 && (!orig || !dir || !rgb_out))) return fail(RTX_E_INVALID, "rtx_trace_rays: bad arguments");
+    if (!c->committed) return fail(RTX_E_STATE, "trace before rtx_commit");
+    if (depth < 0 || depth > RTX_MAX_DEPTH) return fail(RTX_E_LIMIT, "depth outside [0, RTX_MAX_DEPTH]");
+    if (n == 0) return RTX_OK;
+    if (int e = bind(c)) return e;
+    float *d_o = nullptr, *d_d = nullptr, *d_c = nullptr;
+    const size_t bytes = sizeof(float) * 3 * (size_t)n;
+    int rc = RTX_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_o, bytes)) != hipSuccess || (e = hipMalloc((void **)&d_d, bytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_c, bytes)) != hipSuccess || (e = hipMemcpy(d_o, orig, bytes, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_d, dir, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = failHip(e, "rtx_trace_rays");
+    } else {
+        DevScene s = c->dev;
+        s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+        hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
+            (e = hipMemcpy(rgb_out, d_c, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = failHip(e, "rtx_trace_rays");
+    }
+    (void)hipFree(d_o), (void)hipFree(d_d), (void)hipFree(d_c);
+    return rc;
+}
+
+int rtx_intersect_rays(rtx_ctx *c, const float *orig, const float *dir, int n, float *out16) {
+    if (!c || n < 0 || (n > 0 && (!orig || !dir || !out16))) return fail(RTX_E_INVALID, "rtx_intersect_rays: bad arguments");
+    if (!c->committed) return fail(RTX_E_STATE, "intersect before rtx_commit");
+    if (n == 0) return RTX_OK;
+    if (int e = bind(c)) return e;
+    float *d_o = nullptr, *d_d = nullptr, *d_c = nullptr;
+    const size_t bytes = sizeof(float) * 3 * (size_t)n, obytes = sizeof(float) * 16 * (size_t)n;
+    int rc = RTX_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_o, bytes)) != hipSuccess || (e = hipMalloc((void **)&d_d, bytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_c, obytes)) != hipSuccess || (e = hipMemcpy(d_o, orig, bytes, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_d, dir, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = failHip(e, "rtx_intersect_rays");
+    } else {
+        DevScene s = c->dev;
+        s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+        hipLaunchKernelGGL(k_intersect_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
+            (e = hipMemcpy(out16, d_c, obytes, hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = failHip(e, "rtx_intersect_rays");
+    }
+    (void)hipFree(d_o), (void)hipFree(d_d), (void)hipFree(d_c);
+    return rc;
+}
+
+}  // extern "C"
