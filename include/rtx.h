@@ -71,14 +71,22 @@ typedef struct rtx_frame {
  * when the context was rendered with statistics enabled (rtx_set_option RTX_OPT_STATS = 1), which
  * costs one atomic per wavefront per counter. */
 typedef struct rtx_stats {
-    uint64_t primary_rays;   /* traceRay calls at full depth                    */
-    uint64_t secondary_rays; /* traceRay calls below it that reach sceneIntersect */
-    uint64_t shadow_rays;    /* sceneIntersect calls from calcLightning         */
-    uint64_t sky_lookups;    /* Sky::getColorAt calls                           */
-    uint64_t mesh_box_hits;  /* rays that passed the mesh bounding box          */
-    uint64_t bvh_node_tests; /* inner-node (two-box) tests                      */
-    uint64_t triangle_tests; /* Moller-Trumbore tests on mesh triangles         */
-    double kernel_ms;        /* device time of the trace kernel(s), HIP events  */
+    uint64_t primary_rays;    /* traceRay calls at full depth                                  */
+    uint64_t secondary_rays;  /* traceRay calls below it that reach sceneIntersect             */
+    uint64_t shadow_rays;     /* sceneIntersect calls from calcLightning                       */
+    uint64_t sky_lookups;     /* Sky::getColorAt calls                                         */
+    uint64_t mesh_box_hits;   /* rays that passed the mesh bounding box                        */
+    uint64_t bvh_node_tests;  /* inner-node (two-box) tests; oracle: non-empty grid cells      */
+    uint64_t triangle_tests;  /* Moller-Trumbore tests on mesh triangles                       */
+    uint64_t triangle_full;   /* ... of which got past the first (u) rejection                 */
+    uint64_t sphere_tests;    /* Sphere::rayIntersect calls                                    */
+    uint64_t loose_tri_tests; /* Triangle::rayIntersect calls on the loose triangles           */
+    uint64_t box_tests;       /* Cube slab tests (scene boxes and the mesh gate)               */
+    uint64_t plane_tests;     /* ray/plane tests (water plane, island plane)                   */
+    uint64_t island_tests;    /* ellipse containment tests                                     */
+    uint64_t lit_lights;      /* light evaluations that were not in shadow (Phong + powf)      */
+    uint64_t reserved[2];
+    double kernel_ms;         /* device time of the trace kernel(s), HIP events                */
 } rtx_stats;
 
 enum rtx_option {

@@ -786,6 +786,7 @@ int rtx_deinterleave_rows_device(rtx_ctx *, const void *, int, int, int, int, vo
 
 int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {
     if (!c || !o) return fail(RTX_E_INVALID, "null argument");
+    memset(o, 0, sizeof *o);
     o->primary_rays = c->stats.primary, o->secondary_rays = c->stats.secondary, o->shadow_rays = c->stats.shadow;
     o->sky_lookups = c->stats.sky, o->mesh_box_hits = c->stats.box_hits;
     o->bvh_node_tests = c->stats.cell_tests;  // for the oracle: non-empty grid cells tested
@@ -932,35 +933,34 @@ int orx_default_scene(rtx_ctx *c, unsigned mask, const char *bunny_obj_path) {
     orx_default_materials(m9);
     if (int e = rtx_set_materials(c, m9, 9)) return e;
     enum { GLASS = 1, MIRROR = 2, GOLD = 3, SILVER = 4, WATER_BOTTOM = 5, ISLAND = 7, WOOD = 8 };
-    // Scene::loadLights inserts (-20,20,20;1.5), (35,50,-25;2.0), (30,20,30;1.7) into an
-    // std::unordered_set<Light*> (src/Scene.cpp:133-139); calcLightning iterates that set
-    // (src/Scene.cpp:64).  libstdc++ links every node that opens a new bucket at the head of its
-    // list, and three 32-byte-apart heap pointers never share one of the 13 buckets, so the
-    // iteration order is the reverse of the insertion order.  The float sums in calcLightning
-    // depend on it in the last bit, so the lights are handed over in that order.
+    // Every category below is an std::unordered_set of heap pointers in the reference; with
+    // libstdc++ and a handful of evenly spaced pointers such a set iterates in REVERSE insertion
+    // order (each node opens a new bucket and is linked at the list head).  The order decides the
+    // float summation order over the lights (src/Scene.cpp:64-78) and which object wins an exact
+    // distance tie (strict `<` in the category loops), so arrays are listed back to front.
     const float lights[12] = {30, 20, 30, 1.7f, 35, 50, -25, 2.0f, -20, 20, 20, 1.5f};
     if (int e = rtx_set_lights(c, lights, 3)) return e;
     if (mask & 1) {
-        const float cx[4] = {-6, -4, -15.0f, 25.0f};
-        const float cy[4] = {(float)-2.8, (float)-3.1, -4.0f + 5, -4.0f + 4};
-        const float cz[4] = {-22, -21, -50.0f, -50.0f};
-        const float r[4] = {1, (float)0.7, 5, 4};
-        const int mat[4] = {SILVER, GLASS, MIRROR, GLASS};
+        const float cx[4] = {25.0f, -15.0f, -4, -6};
+        const float cy[4] = {-4.0f + 4, -4.0f + 5, (float)-3.1, (float)-2.8};
+        const float cz[4] = {-50.0f, -50.0f, -21, -22};
+        const float r[4] = {4, 5, (float)0.7, 1};
+        const int mat[4] = {GLASS, MIRROR, GLASS, SILVER};
         if (int e = rtx_set_spheres(c, cx, cy, cz, r, mat, 4)) return e;
     }
     if (mask & 2) {
-        const float a[8][3] = {{-6, -4, -28}, {-3, -4, -28}, {0, -4, -28}, {3, -4, -28}, {3, -4, -28},
-                               {-7, 1.5f, -28}, {-7, -1.5f, -28}, {-8, -4, -20}};
-        const float b[8][3] = {{-5, 3, -29}, {-2, 3, -29}, {1, 3, -29}, {4, 3, -29}, {4, 3, -29},
-                               {5, 2.5f, -29}, {5, -0.5f, -29}, {-2, -3.75f, -23}};
+        const float a[8][3] = {{-8, -4, -20}, {-7, -1.5f, -28}, {-7, 1.5f, -28}, {3, -4, -28}, {3, -4, -28},
+                               {0, -4, -28}, {-3, -4, -28}, {-6, -4, -28}};
+        const float b[8][3] = {{-2, -3.75f, -23}, {5, -0.5f, -29}, {5, 2.5f, -29}, {4, 3, -29}, {4, 3, -29},
+                               {1, 3, -29}, {-2, 3, -29}, {-5, 3, -29}};
         const int mat[8] = {WOOD, WOOD, WOOD, WOOD, WOOD, WOOD, WOOD, WOOD};
         if (int e = rtx_set_boxes(c, &a[0][0], &b[0][0], mat, 8)) return e;
     }
     if (mask & 4) {
-        const float t[4][9] = {{-8, -3.75f, -20, -8, -3.75f, -23, -8, -1, -23},
-                               {-8, -3.75f, -20, -8, -1, -23, -8, -3.75f, -23},
+        const float t[4][9] = {{-8, -3.75f, -23, -8, -1, -23, -2, -3.75f, -23},
                                {-8, -3.75f, -23, -2, -3.75f, -23, -8, -1, -23},
-                               {-8, -3.75f, -23, -8, -1, -23, -2, -3.75f, -23}};
+                               {-8, -3.75f, -20, -8, -1, -23, -8, -3.75f, -23},
+                               {-8, -3.75f, -20, -8, -3.75f, -23, -8, -1, -23}};
         const int mat[4] = {WOOD, WOOD, WOOD, WOOD};
         if (int e = rtx_set_triangles(c, &t[0][0], mat, 4)) return e;
     }
@@ -975,7 +975,7 @@ int orx_default_scene(rtx_ctx *c, unsigned mask, const char *bunny_obj_path) {
         if (e) return e;
     }
     if (mask & 16) {
-        const float isl[16] = {0.0f, -25.0f, 12, 8, -15.0f, -50.0f, 12, 15, 25.0f, -50.0f, 10, 12, 15.0f, -100.0f, 15, 12};
+        const float isl[16] = {15.0f, -100.0f, 15, 12, 25.0f, -50.0f, 10, 12, -15.0f, -50.0f, 12, 15, 0.0f, -25.0f, 12, 8};
         V3 lg = v3(136, 204, 0) * 0.3f / 255.0f, dg = v3(102, 153, 0) * 0.3f / 255.0f;
         const float l3[3] = {lg.x, lg.y, lg.z}, d3[3] = {dg.x, dg.y, dg.z};
         if (int e = rtx_set_islands(c, isl, 4, -4.0f, ISLAND, l3, d3)) return e;

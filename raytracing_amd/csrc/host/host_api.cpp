@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../../include/rt_host.h"
+#include "host_error.hpp"
 #include "scene.hpp"
 
 namespace {
@@ -16,6 +17,11 @@ int hostFail(const std::string &msg) {
     return -1;
 }
 
+}  // namespace
+
+void rt::setHostError(const std::string &msg) { g_host_err = msg; }
+
+namespace {
 // command-line errors of the reference (include/ParseException.h, src/ParseException.cpp)
 struct ParseException {
     enum Type { NOT_ENOUGH, SAME_ARGS } type;

@@ -13,6 +13,15 @@
 namespace rt {
 
 // ---- hard-coded scene, src/Scene.cpp:108-166 -------------------------------------------------
+//
+// Order matters.  The reference keeps every category in an std::unordered_set of heap pointers
+// and the per-category loops accept only a strictly nearer hit, so among hits at exactly the same
+// distance the object met first wins (for example a ray that starts inside both a fence post and a
+// rail "hits" both at distance 0 and takes its normal from the first).  With libstdc++ a node that
+// opens a new bucket is linked at the head of the element list, and the handful of equally spaced
+// heap pointers of one category never share one of the set's 13 buckets, so each set iterates in
+// REVERSE insertion order.  The arrays below are therefore filled back to front: element 0 is the
+// object the reference inserted last.
 
 Spheres Scene::loadSpheres() const {
     Spheres s;
@@ -20,10 +29,10 @@ Spheres Scene::loadSpheres() const {
         s.cx.push_back(x), s.cy.push_back(y), s.cz.push_back(z), s.r.push_back(r);
         s.mat.push_back(materials.index(mat));
     };
-    add(-6, (float)-2.8, -22, 1, "silver");
-    add(-4, (float)-3.1, -21, (float)0.7, "glass");
-    add(-15.0f, -4.0f + 5, -50.0f, 5, "mirror");
     add(25.0f, -4.0f + 4, -50.0f, 4, "glass");
+    add(-15.0f, -4.0f + 5, -50.0f, 5, "mirror");
+    add(-4, (float)-3.1, -21, (float)0.7, "glass");
+    add(-6, (float)-2.8, -22, 1, "silver");
     return s;
 }
 
@@ -35,26 +44,23 @@ Boxes Scene::loadCubes() const {
         b.b.insert(b.b.end(), {bx, by, bz});
         b.mat.push_back(wood);
     };
-    // the fence: five posts (the fourth is listed twice in the reference) and two rails
-    add(-6, -4, -28, -5, 3, -29);
-    add(-3, -4, -28, -2, 3, -29);
-    add(0, -4, -28, 1, 3, -29);
-    add(3, -4, -28, 4, 3, -29);
-    add(3, -4, -28, 4, 3, -29);
-    add(-7, 1.5f, -28, 5, 2.5f, -29);
-    add(-7, -1.5f, -28, 5, -0.5f, -29);
     // the slab under the wedge
     add(-8, -4, -20, -2, -3.75f, -23);
+    // the fence: two rails, then five posts (one of them is listed twice in the reference)
+    add(-7, -1.5f, -28, 5, -0.5f, -29);
+    add(-7, 1.5f, -28, 5, 2.5f, -29);
+    add(3, -4, -28, 4, 3, -29);
+    add(3, -4, -28, 4, 3, -29);
+    add(0, -4, -28, 1, 3, -29);
+    add(-3, -4, -28, -2, 3, -29);
+    add(-6, -4, -28, -5, 3, -29);
     return b;
 }
 
 Lights Scene::loadLights() const {
-    // The reference inserts (-20,20,20;1.5), (35,50,-25;2.0), (30,20,30;1.7) into an
-    // std::unordered_set<Light*> (src/Scene.cpp:133-139) and calcLightning iterates that set
-    // (src/Scene.cpp:64).  With libstdc++ a node that opens a new bucket is linked at the head of
-    // the element list, and three heap pointers 32 bytes apart never share one of the set's 13
-    // buckets, so the set iterates in reverse insertion order.  The diffuse and specular sums are
-    // float additions in that order, hence the order below.
+    // inserted as (-20,20,20;1.5), (35,50,-25;2.0), (30,20,30;1.7) (src/Scene.cpp:133-139) and
+    // visited by calcLightning (src/Scene.cpp:64) in reverse, see above; the diffuse and specular
+    // sums are float additions in visiting order
     Lights l;
     l.xyzi = {30, 20, 30, (float)1.7, 35, 50, -25, (float)2.0, -20, 20, 20, (float)1.5};
     return l;
@@ -71,16 +77,16 @@ Triangles Scene::loadTriangles() const {
         t.v.insert(t.v.end(), r, r + 3);
         t.mat.push_back(wood);
     };
-    add(A, B, C);
-    add(A, C, B);
-    add(B, D, C);
     add(B, C, D);
+    add(B, D, C);
+    add(A, C, B);
+    add(A, B, C);
     return t;
 }
 
 Islands Scene::loadIslands() const {
     Islands is;
-    is.cx_cz_a_b = {0.0f, -25.0f, 12, 8, -15.0f, -50.0f, 12, 15, 25.0f, -50.0f, 10, 12, 15.0f, -100.0f, 15, 12};
+    is.cx_cz_a_b = {15.0f, -100.0f, 15, 12, 25.0f, -50.0f, 10, 12, -15.0f, -50.0f, 12, 15, 0.0f, -25.0f, 12, 8};
     is.plane_y = -4.0f;
     is.mat = materials.index("island");
     const float lg[3] = {136, 204, 0}, dg[3] = {102, 153, 0};

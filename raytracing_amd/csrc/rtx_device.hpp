@@ -104,8 +104,13 @@ struct DevScene {
     int prune;       // skip children whose weight is exactly 0
 };
 
-struct Counters {  // one 64-bit slot each; see rtx_stats in rtx.h
-    unsigned long long primary, secondary, shadow, sky, box_hits, node_tests, tri_tests;
+// Statistics slots, in the order of rtx_stats' 64-bit fields (include/rtx.h).
+enum CounterSlot {
+    CNT_PRIMARY, CNT_SECONDARY, CNT_SHADOW, CNT_SKY, CNT_BOX_HITS, CNT_NODE_TESTS, CNT_TRI_TESTS, CNT_TRI_FULL,
+    CNT_SPHERE_TESTS, CNT_LOOSE_TRI_TESTS, CNT_BOX_TESTS, CNT_PLANE_TESTS, CNT_ISLAND_TESTS, CNT_LIT, CNT_SLOTS = 16
+};
+struct Counters {
+    unsigned long long v[CNT_SLOTS];
 };
 
 struct Hit {
@@ -131,13 +136,14 @@ RTX_DEV bool sphereHit(V3 center, float radius, V3 orig, V3 dir, float &dist) {
 
 // Triangle::rayIntersect, src/SceneObjects.cpp:28-49, on precomputed edges (edge1 = v1 - v0 and
 // edge2 = v2 - v0 are the same float subtractions the reference performs per call).
-RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist) {
+RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist, bool *past_u = nullptr) {
     V3 pvec = cross(dir, edge2);
     float det = dot(edge1, pvec);
     if (det < kEps) return false;
     V3 tvec = orig - v0;
     float u = dot(tvec, pvec);
     if (u < 0 || u > det) return false;
+    if (past_u) *past_u = true;
     V3 qvec = cross(tvec, edge1);
     float v = dot(dir, qvec);
     if (v < 0 || u + v > det) return false;

@@ -5,6 +5,7 @@
 // rtx_device.hpp).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -52,13 +53,11 @@ RTX_DEV unsigned char toByte(float c) { return (unsigned char)(255 * fmaxf(0.0f,
 template <bool STATS>
 RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
     if constexpr (STATS) {
-        unsigned v[7] = {lc.primary, lc.secondary, lc.shadow, lc.sky, lc.box_hits, lc.node_tests, lc.tri_tests};
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(out);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            unsigned long long x = v[k];
+        for (int k = 0; k < CNT_SLOTS; ++k) {
+            unsigned long long x = lc.v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&o[k], x);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out->v[k], x);
         }
     }
 }
@@ -534,8 +533,8 @@ int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {
     if (c->stats) {
         Counters h;
         HIP_OR_FAIL(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
-        o->primary_rays = h.primary, o->secondary_rays = h.secondary, o->shadow_rays = h.shadow, o->sky_lookups = h.sky;
-        o->mesh_box_hits = h.box_hits, o->bvh_node_tests = h.node_tests, o->triangle_tests = h.tri_tests;
+        static_assert(offsetof(rtx_stats, kernel_ms) == sizeof(uint64_t) * CNT_SLOTS, "rtx_stats layout");
+        memcpy(o, h.v, sizeof(uint64_t) * CNT_SLOTS);  // slots are in rtx_stats field order
     }
     return RTX_OK;
 }

@@ -5,15 +5,19 @@
 
 namespace rtx {
 
+// Per-lane statistics; they exist only in the STATS instantiation (static indices keep them in
+// registers) and are summed per wave into the global Counters at the end of the kernel.
 template <bool STATS>
 struct LaneCounters {
-    unsigned primary = 0, secondary = 0, shadow = 0, sky = 0, box_hits = 0, node_tests = 0, tri_tests = 0;
+    unsigned v[CNT_SLOTS] = {};
 };
 template <>
 struct LaneCounters<false> {};
 
-#define RTX_COUNT(field) \
-    if constexpr (STATS) lc.field++
+#define RTX_COUNT(slot) \
+    if constexpr (STATS) lc.v[slot]++
+#define RTX_COUNT_N(slot, n) \
+    if constexpr (STATS) lc.v[slot] += (n)
 
 // ---------------------------------------------------------------------------------------------
 // Mesh: LBVH traversal.  Returns the closest front-facing hit under Triangle::rayIntersect with
@@ -28,7 +32,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, in
     // the gate: Model::boxIntersect on the padded vertex bounds, src/SceneObjects.cpp:356
     float gate_near = 0.0f;
     if (!boxSlab(s.mesh_lo, s.mesh_hi, orig, dir, gate_near)) return false;
-    RTX_COUNT(box_hits);
+    RTX_COUNT(CNT_BOX_HITS);
 
     // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
     // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
@@ -41,7 +45,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, in
         const float4 *np = reinterpret_cast<const float4 *>(s.bvh + node);
         const float4 a = np[0], b = np[1], c = np[2];
         const int4 ch = *reinterpret_cast<const int4 *>(np + 3);
-        RTX_COUNT(node_tests);
+        RTX_COUNT(CNT_NODE_TESTS);
         float tnL, tfL, tnR, tfR;
         {
             float t0 = __builtin_fmaf(a.x, ix, ox), t1 = __builtin_fmaf(a.w, ix, ox);
@@ -68,9 +72,13 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, in
                 const int ti = ~child;
                 const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
                 const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                RTX_COUNT(tri_tests);
+                RTX_COUNT(CNT_TRI_TESTS);
                 float t = 0.0f;
-                if (triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t) && t < best_t) {
+                bool past_u = false;
+                const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
+                                       STATS ? &past_u : nullptr);
+                if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
+                if (th && t < best_t) {
                     best_t = t;
                     best_tri = ti;
                     if (SHADOW && t < t_exit) return true;
@@ -118,6 +126,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     int kind = 0, index = -1;
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
+    RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
     for (int i = 0; i < s.n_spheres; ++i) {
         const float4 sp = s.spheres[i];
         float curDist = 0.0f;
@@ -131,6 +140,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
         return true;
     }
     // trianglesIntersect, :304-317
+    RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
     for (int i = 0; i < s.n_tris; ++i) {
         const float *t = s.tris + 9 * i;
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
@@ -141,6 +151,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
         }
     }
     // cubesIntersect, :382-397
+    RTX_COUNT_N(CNT_BOX_TESTS, s.n_boxes);
     for (int i = 0; i < s.n_boxes; ++i) {
         const float *b = s.boxes + 6 * i;
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
@@ -156,6 +167,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     }
     // modelsIntersect, :350-380
     if (s.n_mesh_tris > 0) {
+        RTX_COUNT(CNT_BOX_TESTS);
         int tri = -1;
         float t = minDist;
         if (meshIntersect<SHADOW, STATS>(s, orig, dir, t, tri, t_exit, stack, stride, lc)) {
@@ -169,6 +181,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     }
     // water plane, src/Scene.cpp:38-54
     if (s.water_w > 0) {
+        RTX_COUNT(CNT_PLANE_TESTS);
         float waterDist = kFltMax;
         if (planeHit(s.water_y, orig, dir, waterDist) && waterDist < minDist) {
             minDist = waterDist;
@@ -181,7 +194,9 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     {
         float islandsDist = kFltMax;
         float dist = 0.0f;
+        RTX_COUNT_N(CNT_PLANE_TESTS, s.n_islands > 0 ? 1 : 0);
         if (s.n_islands > 0 && planeHit(s.island_y, orig, dir, dist)) {
+            RTX_COUNT_N(CNT_ISLAND_TESTS, s.n_islands);
             const V3 pt = orig + dir * dist;
             for (int i = 0; i < s.n_islands; ++i) {
                 const float4 is = s.islands[i];  // cx, cz, a, b
@@ -296,7 +311,7 @@ RTX_DEV void calcLighting(const DevScene &s, V3 dir, V3 point, V3 N, float specu
         const float t_exit = fminf(lightDist * 0.999f, s.far_clip);
         Hit dummy;
         float minDist;
-        RTX_COUNT(shadow);
+        RTX_COUNT(CNT_SHADOW);
         bool occluded = false;
         if (sceneIntersect<true, STATS>(s, shadowOrig, lightDir, dummy, minDist, t_exit, stack, stride, lc)) {
             if (minDist < t_exit) {
@@ -307,6 +322,7 @@ RTX_DEV void calcLighting(const DevScene &s, V3 dir, V3 point, V3 N, float specu
             }
         }
         if (occluded) continue;
+        RTX_COUNT(CNT_LIT);
         if (ndl >= 0) Ld += L.w * ndl;
         const float specIntDot = dot(-reflect(-lightDir, N), dir);
         if (specIntDot >= 0) Ls += powf(specIntDot, specular_exp) * L.w;
@@ -340,17 +356,14 @@ RTX_DEV V3 traceRay(const DevScene &s, V3 orig, V3 dir, int depth, int *stack, i
         Hit h;
         if (depth > 0) {
             if constexpr (STATS) {
-                if (depth == fullDepth)
-                    lc.primary++;
-                else
-                    lc.secondary++;
+                lc.v[depth == fullDepth ? CNT_PRIMARY : CNT_SECONDARY]++;
             }
             float md;
             hit = sceneIntersect<false, STATS>(s, orig, dir, h, md, 0.0f, stack, stride, lc);
         }
         bool descended = false;
         if (!hit) {
-            RTX_COUNT(sky);
+            RTX_COUNT(CNT_SKY);
             color = skyColor(s, dir);
         } else {
             float Ld, Ls;

@@ -35,10 +35,18 @@ class Frame(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("sky_lookups", C.c_uint64), ("mesh_box_hits", C.c_uint64), ("bvh_node_tests", C.c_uint64),
-                ("triangle_tests", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("triangle_tests", C.c_uint64), ("triangle_full", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("loose_tri_tests", C.c_uint64), ("box_tests", C.c_uint64), ("plane_tests", C.c_uint64),
+                ("island_tests", C.c_uint64), ("lit_lights", C.c_uint64), ("reserved", C.c_uint64 * 2),
+                ("kernel_ms", C.c_double)]
+
+    @property
+    def rays(self):
+        """sceneIntersect-equivalent queries traced: primary + secondary + shadow"""
+        return self.primary_rays + self.secondary_rays + self.shadow_rays
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
 
 
 # every symbol include/rtx.h and include/rt_host.h declare; the test suite checks the libraries export them all

@@ -1,0 +1,168 @@
+"""Regenerates the golden vectors in this directory from the reference itself.
+
+Run in the build container (needs /root/reference and `make -C oracle ref`):
+    python tests/golden/make_golden.py
+
+Everything written here is data produced by calling the reference's own, unmodified functions
+through oracle/_ref/libref.so (see oracle/ref_harness.cpp): rendered frames, ray-level known
+answers, decoded-texture digests.  No reference source text is stored.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+L = C.CDLL(oracle.REF_LIB_PATH)
+L.ref_scene_create.restype = C.c_void_p
+L.ref_scene_create.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_char_p]
+L.ref_scene_destroy.argtypes = [C.c_void_p]
+L.ref_render.restype = C.c_double
+L.ref_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+L.ref_save_bmp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+L.ref_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+L.ref_scene_intersect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+L.ref_sky.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+L.ref_primary_dirs.argtypes = [C.c_int, C.c_int, C.c_void_p]
+L.ref_refract.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+L.ref_decode_jpeg.restype = C.c_void_p
+L.ref_decode_jpeg.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+L.ref_free.argtypes = [C.c_void_p]
+L.ref_set_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+
+RES = oracle.REF_RESOURCES
+
+
+def scene(mask, sky="envmap.jpg"):
+    h = L.ref_scene_create(oracle.REF_RUN_DIR.encode(), mask, os.path.join(RES, sky).encode(),
+                           os.path.join(RES, "water.jpg").encode())
+    assert h, "reference scene failed to load"
+    # The reference iterates unordered sets of heap pointers; the harness allocates from a fresh
+    # arena so that, as in the reference binary, every set runs in reverse insertion order.  The
+    # golden vectors are only meaningful for that order, so check it.
+    out = np.zeros((16, 6), np.float32)
+    n = L.ref_set_order(h, 4, out.ctypes.data, 16)
+    assert n == 3 and out[:3, 3].tolist() == [np.float32(1.7), 2.0, 1.5], "light order is not reverse insertion"
+    if mask & 2:
+        n = L.ref_set_order(h, 1, out.ctypes.data, 16)
+        assert n == 8 and out[0, :3].tolist() == [-8.0, -4.0, -23.0] and out[7, :3].tolist() == [-6.0, -4.0, -29.0]
+    if mask & 1:
+        n = L.ref_set_order(h, 0, out.ctypes.data, 16)
+        assert n == 4 and out[0, :3].tolist() == [25.0, 0.0, -50.0] and out[3, 0] == -6.0
+    return h
+
+
+def render(h, W, H, depth):
+    buf = np.zeros((H, W, 3), np.uint8)
+    L.ref_render(h, W, H, depth, 8, buf.ctypes.data)
+    return buf
+
+
+def bmp_sha(img):
+    path = "/tmp/_golden.bmp"
+    L.ref_save_bmp(img.ctypes.data, img.shape[1], img.shape[0], path.encode())
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def main():
+    frames = {}
+    small = {}
+    # tag: (mask, W, H, depth, sky, keep pixels?)
+    configs = {
+        "G1": (31, 800, 600, 4, "envmap.jpg", True),     # the reference's own default frame
+        "G1a": (31, 800, 600, 1, "envmap.jpg", False),
+        "G1b": (31, 800, 600, 2, "envmap.jpg", False),
+        "G3": (31, 800, 600, 4, "map.jpg", False),
+        "G4": (17, 800, 600, 1, "envmap.jpg", False),
+        "G5": (8, 800, 600, 4, "envmap.jpg", False),
+        "G4k": (17, 3840, 2160, 1, "envmap.jpg", False),
+        "G5k": (8, 3840, 2160, 4, "envmap.jpg", False),
+        "G2": (31, 3840, 2160, 4, "envmap.jpg", False),
+        # small frames whose pixels are committed (the GPU box has no reference to render them)
+        "S_full_d4": (31, 400, 300, 4, "envmap.jpg", True),
+        "S_full_d4_map": (31, 400, 300, 4, "map.jpg", True),
+        "S_full_d2": (31, 400, 300, 2, "envmap.jpg", True),
+        "S_planes_d1": (17, 400, 300, 1, "envmap.jpg", True),
+        "S_bunny_d4": (8, 400, 300, 4, "envmap.jpg", True),
+        "S_ragged": (31, 333, 217, 3, "map.jpg", True),
+    }
+    cache = {}
+    for tag, (mask, W, H, d, sky, keep) in configs.items():
+        key = (mask, sky)
+        if key not in cache:
+            cache[key] = scene(mask, sky)
+        img = render(cache[key], W, H, d)
+        frames[tag] = {"mask": mask, "width": W, "height": H, "depth": d, "envmap": sky, "bmp_sha256": bmp_sha(img)}
+        if keep:
+            small[tag] = img
+        print(tag, frames[tag]["bmp_sha256"], flush=True)
+    # the unmodified reference binary must agree with the harness on the one frame it can render
+    run = subprocess.run([oracle.REF_BIN_PATH, "-out", "/tmp/_golden_rt.bmp", "-scene", "1", "-threads", "8"],
+                         cwd=oracle.REF_RUN_DIR, capture_output=True)
+    assert run.returncode == 0
+    binary_sha = hashlib.sha256(open("/tmp/_golden_rt.bmp", "rb").read()).hexdigest()
+    assert binary_sha == frames["G1"]["bmp_sha256"], "harness and reference binary disagree"
+    frames["G1"]["from_unmodified_binary"] = True
+    json.dump(frames, open(os.path.join(HERE, "frames.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "frames_small.npz"), **small)
+
+    # ---- ray-level known answers on the full scene (map.jpg sky: small enough for the GPU box) ----
+    rng = np.random.default_rng(20251111)
+    h = cache[(31, "map.jpg")]
+    n = 40000
+    cam = np.array([-7.5, 8, -5], np.float32)
+    d = rng.normal(size=(n, 3))
+    d[: n // 2, 1] = -np.abs(d[: n // 2, 1]) * 0.3      # half look down at the scene
+    d[: n // 2, 2] = -np.abs(d[: n // 2, 2])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.ascontiguousarray(d, np.float32)
+    o = np.tile(cam, (n, 1)).astype(np.float32)
+    # a quarter of the rays start at random points around the objects instead of the camera
+    o[n // 2: 3 * n // 4] = rng.uniform([-20, -4.4, -60], [30, 6, -15], size=(n // 4, 3)).astype(np.float32)
+    o = np.ascontiguousarray(o)
+    isect = np.zeros((n, 16), np.float32)
+    L.ref_scene_intersect(h, n, o.ctypes.data, d.ctypes.data, isect.ctypes.data)
+    rgb4 = np.zeros((n, 3), np.float32)
+    L.ref_trace(h, n, o.ctypes.data, d.ctypes.data, 4, rgb4.ctypes.data)
+    rgb1 = np.zeros((n, 3), np.float32)
+    L.ref_trace(h, n, o.ctypes.data, d.ctypes.data, 1, rgb1.ctypes.data)
+    sky = np.zeros((n, 3), np.float32)
+    L.ref_sky(h, n, d.ctypes.data, sky.ctypes.data)
+    # refract: unit I, unit N, both orders of media, including total internal reflection
+    I = rng.normal(size=(4000, 3)); I /= np.linalg.norm(I, axis=1, keepdims=True)
+    N = rng.normal(size=(4000, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    I = np.ascontiguousarray(I, np.float32); N = np.ascontiguousarray(N, np.float32)
+    refr = np.zeros((4000, 3), np.float32)
+    L.ref_refract(4000, I.ctypes.data, N.ctypes.data, 1.5, refr.ctypes.data)
+    # primary directions of a small frame
+    dirs = np.zeros((60, 80, 3), np.float32)
+    L.ref_primary_dirs(80, 60, dirs.ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "kats.npz"), orig=o, dir=d, isect=isect, rgb_d4=rgb4, rgb_d1=rgb1, sky=sky,
+                        refr_I=I, refr_N=N, refr_out=refr, primary_dirs_80x60=dirs)
+
+    # ---- decoded-texture digests (the reference's JPEG decoder on every JPEG it ships) ----
+    tex = {}
+    for name in sorted(os.listdir(RES)):
+        if not name.lower().endswith((".jpg", ".jpeg")) or name == "map2.jpg":
+            continue
+        w, hh, nn = C.c_int(), C.c_int(), C.c_int()
+        p = L.ref_decode_jpeg(os.path.join(RES, name).encode(), w, hh, nn)
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(hh.value, w.value, nn.value))
+        tex[name] = {"shape": [hh.value, w.value, nn.value], "sha256": hashlib.sha256(a.tobytes()).hexdigest(),
+                     "crc32_rows_0_7": zlib.crc32(a[:8].tobytes())}
+        L.ref_free(p)
+    json.dump(tex, open(os.path.join(HERE, "textures.json"), "w"), indent=1, sort_keys=True)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
