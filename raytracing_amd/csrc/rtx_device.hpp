@@ -35,12 +35,12 @@ RTX_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // func_geometric.inl:68-79
 RTX_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 // v * (1 / sqrt(dot(v, v))): func_geometric.inl:82-90, func_exponential.inl:44-50
-RTX_DEV V3 normalize(V3 v) { return v * (1.0f / __fsqrt_rn(dot(v, v))); }
+RTX_DEV V3 normalize(V3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 // I - N * dot(N, I) * 2: func_geometric.inl:104-110
 RTX_DEV V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0f; }
 RTX_DEV float distance(V3 p0, V3 p1) {
     V3 d = p1 - p0;
-    return __fsqrt_rn(dot(d, d));
+    return sqrtf(dot(d, d));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -129,7 +129,7 @@ RTX_DEV bool sphereHit(V3 center, float radius, V3 orig, V3 dir, float &dist) {
     float dSquared = dot(diff, diff) - t0 * t0;
     float radius2 = radius * radius;
     if (dSquared > radius2) return false;
-    float t1 = __fsqrt_rn(radius2 - dSquared);
+    float t1 = sqrtf(radius2 - dSquared);
     dist = t0 > t1 + kEps ? t0 - t1 : t0 + t1;
     return dist > kEps;
 }
@@ -151,11 +151,15 @@ RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist, boo
     return dist > kEps;
 }
 
-// glm::triangleNormal = normalize(cross(p1 - p2, p1 - p3)), include/glm/gtx/normal.inl:5-14.
-// With e1 = v1 - v0, e2 = v2 - v0: v0 - v1 = -e1 and v0 - v2 = -e2 exactly, and the products of
-// two negated factors equal the products of the factors, so cross(-e1, -e2) == cross(e1, e2)
-// bit for bit.
-RTX_DEV V3 triNormal(V3 edge1, V3 edge2) { return normalize(cross(edge1, edge2)); }
+// glm::triangleNormal = normalize(cross(p1 - p2, p1 - p3)), include/glm/gtx/normal.inl:5-14, from
+// the stored edges e1 = v1 - v0, e2 = v2 - v0.  v0 - v1 is -(v1 - v0) exactly, except that equal
+// coordinates give +0 both ways round; 0.0f - e reproduces that (0 - (+0) = +0, 0 - x = -x), so
+// the normal comes out with the reference's signed zeros too.
+RTX_DEV V3 triNormal(V3 edge1, V3 edge2) {
+    const V3 a = v3(0.0f - edge1.x, 0.0f - edge1.y, 0.0f - edge1.z);
+    const V3 b = v3(0.0f - edge2.x, 0.0f - edge2.y, 0.0f - edge2.z);
+    return normalize(cross(a, b));
+}
 
 // Cube::rayIntersect(orig, dir, nearDist, farDist), src/SceneObjects.cpp:101-139.  An origin
 // inside the box returns true WITHOUT writing nearDist (the caller's 0 stays: "hit at distance 0").
@@ -256,7 +260,7 @@ RTX_DEV V3 refractDir(V3 I, V3 N, float etat) {
     float eta = etai / etat;
     float k = 1 - eta * eta * (1 - cosi * cosi);
     if (k < 0) return v3(1, 0, 0);
-    return I * eta + N * (eta * cosi - __fsqrt_rn(k));
+    return I * eta + N * (eta * cosi - sqrtf(k));
 }
 
 }  // namespace rtx

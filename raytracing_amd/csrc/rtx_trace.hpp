@@ -37,7 +37,12 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, in
     // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
     // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
     // accept is never culled by rounding here.
-    const float ix = __builtin_amdgcn_rcpf(dir.x), iy = __builtin_amdgcn_rcpf(dir.y), iz = __builtin_amdgcn_rcpf(dir.z);
+    // A zero direction component would give 1/0 = inf and then inf - inf = NaN in b*inv - o*inv;
+    // clamping the reciprocal to +-1e30 keeps every product finite and the slab logic intact (the
+    // ray is then "almost" parallel: inside the slab it spans (-huge, +huge), outside it misses).
+    const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.x), -1e30f, 1e30f);
+    const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.y), -1e30f, 1e30f);
+    const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.z), -1e30f, 1e30f);
     const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
     int sp = 0;
     int node = 0;

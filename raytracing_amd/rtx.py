@@ -303,5 +303,18 @@ def hip_backend():
     """The product backend.  Raises if librtx_hip.so has not been built: there is no fallback."""
     global _hip
     if _hip is None:
+        _load_torch_first()
         _hip = Backend(HIP_LIB_PATH)
     return _hip
+
+
+def _load_torch_first():
+    """PyTorch wheels bundle their own copy of the HIP runtime.  A process must not end up with two
+    runtimes (the second one sees no GPUs), so when torch is installed it is imported before
+    librtx_hip.so, whose libamdhip64 dependency then resolves to the runtime torch already loaded."""
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass

@@ -41,7 +41,8 @@ def oracle_backend():
 @pytest.fixture(scope="session")
 def hip():
     """The product library.  GPU tests fail (not skip) if it is missing: no fallback exists."""
-    return Backend(HIP_LIB_PATH)
+    from raytracing_amd.rtx import hip_backend
+    return hip_backend()
 
 
 @pytest.fixture(scope="session")
