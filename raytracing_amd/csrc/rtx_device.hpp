@@ -85,6 +85,9 @@ struct DevScene {
     int n_mesh_tris;
     int mesh_mat;
     float mesh_lo[3], mesh_hi[3];  // the gate box: all vertices -/+ 1e-4
+    // conservative bounds of whole categories (lo xyz, hi xyz), padded: a ray that misses one
+    // cannot hit anything inside, so the exact per-primitive tests are skipped for it
+    float sphere_bounds[6], tri_bounds[6], box_bounds[6];
     // islands
     const float4 *islands;  // cx, cz, a, b
     int n_islands;
@@ -193,6 +196,26 @@ RTX_DEV bool boxSlab(const float lo[3], const float hi[3], V3 orig, V3 dir, floa
     return true;
 }
 
+// Conservative ray/box filter.  Uses the same (bound - origin) differences as the exact slab test
+// but multiplies by an approximate reciprocal (clamped to +-1e30 so that a zero direction component
+// gives a huge finite number, never inf * 0) and widens the far side by 2e-6, more than the
+// rounding difference between this and the exact IEEE divisions.  It never rejects a ray that
+// boxSlab accepts (an origin inside the box gives t_near <= 0 <= t_far here as well).
+RTX_DEV bool slabMaybe(const float lo[3], const float hi[3], V3 o, V3 inv) {
+    const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tn <= tf * 1.000002f;
+}
+
+RTX_DEV V3 safeInverse(V3 d) {
+    return v3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f),
+              __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f),
+              __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f));
+}
+
 // float -> int the way the reference's x86-64 build converts (cvttss2si): NaN and out-of-range
 // give INT_MIN.  The plain device conversion saturates instead.
 RTX_DEV int truncToInt(float v) {
@@ -232,10 +255,13 @@ RTX_DEV V3 boxNormal(const float lo[3], const float hi[3], V3 hit) {
 // and dot(p0 - orig, n) equals plane_y - orig.y whenever the other components are finite (adding
 // a signed zero changes nothing but the sign of a zero, which neither comparison below sees).
 RTX_DEV bool planeHit(float plane_y, V3 orig, V3 dir, float &dist) {
-    float d = dir.y;
-    if (fabsf(d) > kEps) {
-        float t = (plane_y - orig.y) / d;
-        if (t > 0.0f) {
+    const float d = dir.y;
+    const float num = plane_y - orig.y;
+    // t = num / d is positive only if num and d have the same sign and num is not zero; deciding
+    // that first skips the IEEE division for every ray that points away from the plane
+    if (fabsf(d) > kEps && num != 0.0f && (__float_as_uint(num) ^ __float_as_uint(d)) < 0x80000000u) {
+        const float t = num / d;
+        if (t > 0.0f) {  // still needed: the quotient of tiny operands can underflow to 0
             dist = t;
             return true;
         }

@@ -5,6 +5,7 @@
 // rtx_device.hpp).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -450,6 +451,34 @@ int rtx_commit(rtx_ctx *c) {
     d.water = dw, d.water_w = c->water_w, d.water_h = c->water_h, d.water_mat = c->water_mat;
     d.water_y = c->water_y, d.water_scale = c->water_scale;
     d.sky = dsk, d.sky_w = c->sky_w, d.sky_h = c->sky_h, d.sky_shift = c->sky_shift;
+
+    // Conservative bounds per category for the cheap ray filter (slabMaybe).  They only have to
+    // contain everything the exact tests can report a hit on; the padding covers the rounding of
+    // those tests (a sphere or triangle test can accept a ray that passes a few ulp outside).
+    {
+        auto reset = [](float b[6]) {
+            for (int k = 0; k < 3; ++k) b[k] = 3.0e38f, b[3 + k] = -3.0e38f;
+        };
+        auto grow = [](float b[6], float x, float y, float z) {
+            const float p[3] = {x, y, z};
+            for (int k = 0; k < 3; ++k) b[k] = p[k] < b[k] ? p[k] : b[k], b[3 + k] = p[k] > b[3 + k] ? p[k] : b[3 + k];
+        };
+        auto pad = [](float b[6]) {
+            for (int k = 0; k < 3; ++k) {
+                const float m = std::fmax(std::fabs(b[k]), std::fabs(b[3 + k]));
+                const float e = 1e-4f * (b[3 + k] - b[k]) + 1e-5f * m + 1e-6f;
+                b[k] -= e, b[3 + k] += e;
+            }
+        };
+        reset(d.sphere_bounds), reset(d.tri_bounds), reset(d.box_bounds);
+        for (const float4 &sp : c->spheres) {
+            const float r = std::fabs(sp.w) * 1.001f;
+            grow(d.sphere_bounds, sp.x - r, sp.y - r, sp.z - r), grow(d.sphere_bounds, sp.x + r, sp.y + r, sp.z + r);
+        }
+        for (size_t i = 0; i + 2 < c->tris.size(); i += 3) grow(d.tri_bounds, c->tris[i], c->tris[i + 1], c->tris[i + 2]);
+        for (size_t i = 0; i + 2 < c->boxes.size(); i += 3) grow(d.box_bounds, c->boxes[i], c->boxes[i + 1], c->boxes[i + 2]);
+        pad(d.sphere_bounds), pad(d.tri_bounds), pad(d.box_bounds);
+    }
 
     const int nt = (int)(c->mesh_idx.size() / 3), nv = (int)(c->mesh_verts.size() / 3);
     d.n_mesh_tris = 0;

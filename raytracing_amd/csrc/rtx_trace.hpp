@@ -27,9 +27,12 @@ struct LaneCounters<false> {};
 // In SHADOW mode the walk stops at the first hit nearer than t_exit.
 // ---------------------------------------------------------------------------------------------
 template <bool SHADOW, bool STATS>
-RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, int &best_tri, float t_exit,
+RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
                            int *stack, int stride, LaneCounters<STATS> &lc) {
-    // the gate: Model::boxIntersect on the padded vertex bounds, src/SceneObjects.cpp:356
+    // the gate: Model::boxIntersect on the padded vertex bounds, src/SceneObjects.cpp:356 -- the
+    // cheap filter first, the reference's own slab test (six IEEE divisions) only for candidates
+    if (!slabMaybe(s.mesh_lo, s.mesh_hi, orig, inv)) return false;
+    RTX_COUNT(CNT_BOX_TESTS);
     float gate_near = 0.0f;
     if (!boxSlab(s.mesh_lo, s.mesh_hi, orig, dir, gate_near)) return false;
     RTX_COUNT(CNT_BOX_HITS);
@@ -37,12 +40,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, float &best_t, in
     // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
     // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
     // accept is never culled by rounding here.
-    // A zero direction component would give 1/0 = inf and then inf - inf = NaN in b*inv - o*inv;
-    // clamping the reciprocal to +-1e30 keeps every product finite and the slab logic intact (the
-    // ray is then "almost" parallel: inside the slab it spans (-huge, +huge), outside it misses).
-    const float ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.x), -1e30f, 1e30f);
-    const float iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.y), -1e30f, 1e30f);
-    const float iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dir.z), -1e30f, 1e30f);
+    const float ix = inv.x, iy = inv.y, iz = inv.z;  // clamped reciprocals: no inf - inf below
     const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
     int sp = 0;
     int node = 0;
@@ -129,53 +127,60 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     float minDist = kFltMax;
     // what was hit last: 0 none, 1 sphere, 2 loose triangle, 3 box, 4 mesh triangle, 5 water, 6 island
     int kind = 0, index = -1;
+    const V3 inv = safeInverse(dir);
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
-    RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
-    for (int i = 0; i < s.n_spheres; ++i) {
-        const float4 sp = s.spheres[i];
-        float curDist = 0.0f;
-        if (sphereHit(v3(sp.x, sp.y, sp.z), sp.w, orig, dir, curDist) && curDist < minDist) {
-            minDist = curDist;
-            kind = 1, index = i;
+    if (s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
+        RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
+        for (int i = 0; i < s.n_spheres; ++i) {
+            const float4 sp = s.spheres[i];
+            float curDist = 0.0f;
+            if (sphereHit(v3(sp.x, sp.y, sp.z), sp.w, orig, dir, curDist) && curDist < minDist) {
+                minDist = curDist;
+                kind = 1, index = i;
+            }
+        }
+        if (SHADOW && minDist < t_exit) {
+            min_dist = minDist;
+            return true;
         }
     }
-    if (SHADOW && minDist < t_exit) {
-        min_dist = minDist;
-        return true;
-    }
     // trianglesIntersect, :304-317
-    RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
-    for (int i = 0; i < s.n_tris; ++i) {
-        const float *t = s.tris + 9 * i;
-        const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
-        float curDist = 0.0f;
-        if (triHit(v0, v1 - v0, v2 - v0, orig, dir, curDist) && curDist < minDist) {
-            minDist = curDist;
-            kind = 2, index = i;
+    if (s.n_tris > 0 && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
+        RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
+        for (int i = 0; i < s.n_tris; ++i) {
+            const float *t = s.tris + 9 * i;
+            const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
+            float curDist = 0.0f;
+            if (triHit(v0, v1 - v0, v2 - v0, orig, dir, curDist) && curDist < minDist) {
+                minDist = curDist;
+                kind = 2, index = i;
+            }
         }
     }
     // cubesIntersect, :382-397
-    RTX_COUNT_N(CNT_BOX_TESTS, s.n_boxes);
-    for (int i = 0; i < s.n_boxes; ++i) {
-        const float *b = s.boxes + 6 * i;
-        const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
-        float curDist = 0.0f;
-        if (boxSlab(lo, hi, orig, dir, curDist) && curDist < minDist) {
-            minDist = curDist;
-            kind = 3, index = i;
+    if (s.n_boxes > 0 && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
+        for (int i = 0; i < s.n_boxes; ++i) {
+            const float *b = s.boxes + 6 * i;
+            const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
+            if (!slabMaybe(lo, hi, orig, inv)) continue;
+            RTX_COUNT(CNT_BOX_TESTS);
+            float curDist = 0.0f;
+            if (boxSlab(lo, hi, orig, dir, curDist) && curDist < minDist) {
+                minDist = curDist;
+                kind = 3, index = i;
+            }
         }
-    }
-    if (SHADOW && minDist < t_exit) {
-        min_dist = minDist;
-        return true;
+        if (SHADOW && minDist < t_exit) {
+            min_dist = minDist;
+            return true;
+        }
     }
     // modelsIntersect, :350-380
     if (s.n_mesh_tris > 0) {
-        RTX_COUNT(CNT_BOX_TESTS);
         int tri = -1;
         float t = minDist;
-        if (meshIntersect<SHADOW, STATS>(s, orig, dir, t, tri, t_exit, stack, stride, lc)) {
+        if (meshIntersect<SHADOW, STATS>(s, orig, dir, inv, t, tri, t_exit, stack, stride, lc)) {
             min_dist = t;
             return true;
         }
@@ -205,11 +210,14 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
             const V3 pt = orig + dir * dist;
             for (int i = 0; i < s.n_islands; ++i) {
                 const float4 is = s.islands[i];  // cx, cz, a, b
-                float xa = (pt.x - is.x) / is.z, zb = (pt.z - is.y) / is.w;
-                if (pt.x > is.x - is.z && pt.x < is.x + is.z && pt.z > is.y - is.w && pt.z < is.y + is.w &&
-                    xa * xa + zb * zb <= 1.0f && dist < minDist) {
-                    islandsDist = dist;
-                    kind = 6, index = i;
+                // the bounding-rectangle conditions come first in the reference's && chain as well; the
+                // two divisions of the ellipse test are only paid inside the rectangle
+                if (pt.x > is.x - is.z && pt.x < is.x + is.z && pt.z > is.y - is.w && pt.z < is.y + is.w && dist < minDist) {
+                    const float xa = (pt.x - is.x) / is.z, zb = (pt.z - is.y) / is.w;
+                    if (xa * xa + zb * zb <= 1.0f) {
+                        islandsDist = dist;
+                        kind = 6, index = i;
+                    }
                 }
             }
         }
