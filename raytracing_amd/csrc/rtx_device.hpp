@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rtx_reftables.hpp"
+
 namespace rtx {
 
 #define RTX_DEV __device__ __forceinline__
@@ -106,6 +108,39 @@ struct DevScene {
     float fprec;     // 1e-3, include/Scene.h:23
     int prune;       // skip children whose weight is exactly 0
 };
+
+// The analytic part of the scene (a few hundred bytes to a few KB) staged in LDS once per block.
+// Every ray of every lane walks these lists; from global memory each list element costs a
+// dependent scalar-load round trip per ray, from LDS a broadcast read.
+constexpr int kMaxMaterials = 32, kMaxLights = 8, kMaxSmallPrims = 16;
+struct SmallScene {
+    Material materials[kMaxMaterials];
+    float4 lights[kMaxLights];
+    float4 spheres[kMaxSmallPrims];
+    float4 islands[kMaxSmallPrims];
+    float tris[kMaxSmallPrims * 9];
+    float boxes[kMaxSmallPrims * 6];
+    int sphere_mat[kMaxSmallPrims], tri_mat[kMaxSmallPrims], box_mat[kMaxSmallPrims];
+    RefMathTables math;  // powf tables (rtx_refmath.hpp), indexed per lane
+};
+
+// cooperative copy by all threads of the block; the caller synchronises afterwards
+__device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s) {
+    const int t = threadIdx.x, n = blockDim.x;
+    auto copy = [&](void *dst, const void *src, int dwords) {
+        for (int i = t; i < dwords; i += n) static_cast<unsigned *>(dst)[i] = static_cast<const unsigned *>(src)[i];
+    };
+    copy(q.materials, s.materials, s.n_materials * 9);
+    copy(q.lights, s.lights, s.n_lights * 4);
+    copy(q.spheres, s.spheres, s.n_spheres * 4);
+    copy(q.sphere_mat, s.sphere_mat, s.n_spheres);
+    copy(q.islands, s.islands, s.n_islands * 4);
+    copy(q.tris, s.tris, s.n_tris * 9);
+    copy(q.tri_mat, s.tri_mat, s.n_tris);
+    copy(q.boxes, s.boxes, s.n_boxes * 6);
+    copy(q.box_mat, s.box_mat, s.n_boxes);
+    copy(&q.math, &kRefMathTables, (int)(sizeof(RefMathTables) / 4));
+}
 
 // Statistics slots, in the order of rtx_stats' 64-bit fields (include/rtx.h).
 enum CounterSlot {

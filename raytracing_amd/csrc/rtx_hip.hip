@@ -21,8 +21,7 @@ using namespace rtx;
 
 namespace {
 
-constexpr int kBlock = 256;     // 4 waves; a block renders a 16x16 pixel tile, a wave an 8x8 quadrant
-constexpr int kTile = 16;
+constexpr int kBlock = 256;     // 4 waves per block
 constexpr int kStackDepth = 32; // LDS traversal stack entries per lane (checked against the tree's depth)
 
 struct DevCamera {
@@ -63,24 +62,88 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
     }
 }
 
-// One lane per pixel.  Block b renders tile (b % tiles_x, b / tiles_x) of the rank's compact
-// image (rows row_first, row_first + row_step, ...); wave w takes the 8x8 quadrant (w & 1, w >> 1)
-// so that the 64 rays of a wave stay close together.
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, int tiles_x,
+// Lane refill inside a wave-owned tile.  A block covers a 32x32-pixel area, each of its four waves
+// a 16x16 quadrant, i.e. a pool of 256 pixel slots (four 8x8 chunks).  Every trip of the loop
+// evaluates one node of each active lane's path (closest hit + shadow rays + shading); a lane whose
+// path is complete writes its pixel and takes the next slot of the wave's pool at the top of the
+// next trip, so lanes that finish early (sky, diffuse surfaces) do not idle while neighbours bounce
+// through glass.  Idle lanes get consecutive slots in lane order (ballot + mbcnt), which keeps the
+// rays of a refill batch adjacent on screen.  The wave leaves when its pool is empty and all lanes
+// are idle; blocks are balanced over the chip by the hardware dispatcher (no global work counter:
+// device-scope atomics on one address serialise at about 10 ns each, far too slow at one per chunk).
+template <bool STATS, int kWaveTile>
+__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, int blocks_x,
+                                                   const unsigned *__restrict__ order,
                                                    unsigned char *__restrict__ out, Counters *counters) {
+    constexpr unsigned kWaveSlots = kWaveTile * kWaveTile;
+    constexpr int kChunksX = kWaveTile / 8;
     __shared__ int s_stack[kStackDepth * kBlock];
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = tile_x * kTile + (wave & 1) * 8 + (lane & 7);
-    const int pk = tile_y * kTile + (wave >> 1) * 8 + (lane >> 3);
+    __shared__ SmallScene q;
+    loadSmallScene(q, s);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    int *stack = s_stack + threadIdx.x;
+    const int wpb = blockDim.x >> 6;  // waves per block: 1 or 4
+    const int bt = (wpb == 4 ? 2 : 1) * kWaveTile;
+    // Blocks are dispatched in blockIdx order; `order` lists the tiles with the expensive ones first
+    // (see tileOrder), so the longest-running waves start at once instead of in the middle of the frame.
+    const unsigned tile = order ? order[blockIdx.x] : blockIdx.x;
+    const int x0 = (int)(tile % (unsigned)blocks_x) * bt + (wave & 1) * kWaveTile;
+    const int y0 = (int)(tile / (unsigned)blocks_x) * bt + (wave >> 1) * kWaveTile;
     LaneCounters<STATS> lc;
-    if (px < fr.width && pk < fr.rows) {
-        const int row = fr.row_first + pk * fr.row_step;
-        const V3 dir = primaryDir(cam, fr.width, fr.height, row, px);
-        const V3 c = traceRay<STATS>(s, v3(cam.ox, cam.oy, cam.oz), dir, fr.depth, s_stack + threadIdx.x, kBlock, lc);
-        unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
-        p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
+    unsigned long long t_begin = 0;
+    if (STATS || (s.prune & 2)) t_begin = __builtin_amdgcn_s_memrealtime();
+    PathState st;
+    bool active = false;
+    int px = 0, pk = 0;
+    unsigned next_slot = 0;  // wave-uniform: first unassigned slot of the pool
+    const V3 eye = v3(cam.ox, cam.oy, cam.oz);
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle && next_slot < kWaveSlots) {
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+            const unsigned slot = next_slot + rank;
+            if (!active && slot < kWaveSlots) {
+                const unsigned chunk = slot >> 6, pos = slot & 63u;
+                px = x0 + (int)(chunk % kChunksX) * 8 + (int)(pos & 7u);
+                pk = y0 + (int)(chunk / kChunksX) * 8 + (int)(pos >> 3);
+                if (px < fr.width && pk < fr.rows) {
+                    const int row = fr.row_first + pk * fr.row_step;
+                    pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
+                    active = true;
+                }
+            }
+            next_slot += (unsigned)__popcll(idle);
+        }
+        if (!__any(active)) {
+            if (next_slot >= kWaveSlots) break;
+            continue;  // the slots handed out lay outside the frame: take the next ones
+        }
+        if (active) {
+            V3 c;
+            if (pathStep<STATS>(s, q, st, c, stack, blockDim.x, lc)) {
+                unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
+                p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
+                active = false;
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // wave lifetime in 100 MHz ticks: slot 14 = longest wave, slot 15 = sum over waves
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_begin;
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&counters->v[14], dt);
+            atomicAdd(&counters->v[15], dt);
+        }
+    }
+    if (s.prune & 2) {  // debug: paint the wave's lifetime (in units of 0.25 us) over its tile
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_begin;
+        const unsigned v = (unsigned)min(dt / 25ull, 65535ull);
+        const int lx = x0 + (int)(threadIdx.x & 7), ly = y0 + (int)((threadIdx.x & 63) >> 3);
+        if (kWaveTile == 8 && lx < fr.width && ly < fr.rows) {
+            unsigned char *p = out + ((size_t)ly * fr.width + lx) * 3;
+            p[0] = (unsigned char)(v & 255), p[1] = (unsigned char)(v >> 8), p[2] = 0;
+        }
     }
     flushCounters<STATS>(lc, counters);
 }
@@ -89,10 +152,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *
                                                        const float *__restrict__ dir, int n, int depth,
                                                        float *__restrict__ rgb) {
     __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ SmallScene q;
+    loadSmallScene(q, s);
+    __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     LaneCounters<false> lc;
-    const V3 c = traceRay<false>(s, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+    const V3 c = traceRay<false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
                                  v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, s_stack + threadIdx.x, kBlock, lc);
     rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
 }
@@ -101,6 +167,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const flo
                                                            const float *__restrict__ dir, int n,
                                                            float *__restrict__ out16) {
     __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ SmallScene q;
+    loadSmallScene(q, s);
+    __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     LaneCounters<false> lc;
@@ -108,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const flo
     h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
     h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
     float md;
-    const bool ok = sceneIntersect<false, false>(s, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+    const bool ok = sceneIntersect<false, false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
                                                  v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), h, md, 0.0f,
                                                  s_stack + threadIdx.x, kBlock, lc);
     float *o = out16 + 16 * (size_t)i;
@@ -199,6 +268,7 @@ struct rtx_ctx {
     int sky_w = 0, sky_h = 0, sky_shift = 100;
     // options
     bool stats = false;
+    int variant = 0;
     int prune = 1;
     float far_clip = 700.0f, fprec = 0.001f;
     // device state
@@ -207,6 +277,10 @@ struct rtx_ctx {
     std::vector<void *> owned;
     int bvh_depth = 0;
     Counters *d_counters = nullptr;
+    // launch order of the tiles, cached for the last (camera, frame, tile size) it was built for
+    unsigned *d_order = nullptr;
+    size_t d_order_cap = 0;
+    std::vector<unsigned char> order_key;
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -242,22 +316,124 @@ DevCamera devCamera(const rtx_camera *cam) {
     return d;
 }
 
+// Screen-space rectangle (pixel columns, image rows) that contains the projection of a world-space
+// box under the camera model of primaryDir: dir ~ M v + k c with v = (x, y, z_focal), k = add_origin.
+// Inverting for a point P: M v = lambda (P - c) - k c, lambda fixed by v.z = z_focal.  Returns false
+// (meaning "anywhere") when a corner is not in front of the image plane.
+bool projectBox(const rtx_camera *cam, int W, int H, const float lo[3], const float hi[3], float rect[4]) {
+    const float *M = cam->basis;
+    const float zf = (float)(-H) / (2.0f * cam->tan_half_fov);
+    float b[3] = {0, 0, 0};
+    if (cam->add_origin)
+        for (int r = 0; r < 3; ++r) b[r] = M[3 * r] * cam->origin[0] + M[3 * r + 1] * cam->origin[1] + M[3 * r + 2] * cam->origin[2];  // (M^T c)[r]
+    rect[0] = rect[2] = 1e30f, rect[1] = rect[3] = -1e30f;
+    for (int k = 0; k < 8; ++k) {
+        const float P[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
+        const float d[3] = {P[0] - cam->origin[0], P[1] - cam->origin[1], P[2] - cam->origin[2]};
+        float a[3];
+        for (int r = 0; r < 3; ++r) a[r] = M[3 * r] * d[0] + M[3 * r + 1] * d[1] + M[3 * r + 2] * d[2];
+        if (std::fabs(a[2]) < 1e-6f) return false;
+        const float lambda = (zf + b[2]) / a[2];
+        if (!(lambda > 0.0f)) return false;
+        const float x = lambda * a[0] - b[0], y = lambda * a[1] - b[1];
+        const float col = x + W / 2.0f - 0.5f, row = H / 2.0f - 0.5f - y;
+        rect[0] = std::fmin(rect[0], col), rect[1] = std::fmax(rect[1], col);
+        rect[2] = std::fmin(rect[2], row), rect[3] = std::fmax(rect[3], row);
+    }
+    return true;
+}
+
+// Launch order of the tiles: those that can see the mesh first, then those that can see a mirror or
+// glass sphere, then the rest -- a longest-job-first schedule from bounding boxes alone.  The frame
+// takes as long as its slowest wave; a wave that walks the mesh at every bounce runs for hundreds of
+// microseconds, and if it only starts halfway through the dispatch the chip idles waiting for it.
+int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int blocks_x, int blocks_y,
+              const unsigned **out) {
+    *out = nullptr;
+    const size_t n = (size_t)blocks_x * blocks_y;
+    std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame) + sizeof(int));
+    memcpy(key.data(), cam, sizeof(rtx_camera));
+    memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
+    memcpy(key.data() + sizeof(rtx_camera) + sizeof(rtx_frame), &bt, sizeof(int));
+    if (key == c->order_key && c->d_order) {
+        *out = c->d_order;
+        return RTX_OK;
+    }
+    struct Rect {
+        float r[4];
+        int cls;
+    };
+    std::vector<Rect> rects;
+    const DevScene &d = c->dev;
+    if (d.n_mesh_tris > 0) {
+        Rect r;
+        r.cls = 0;
+        if (projectBox(cam, f->width, f->height, d.mesh_lo, d.mesh_hi, r.r)) rects.push_back(r);
+        else return RTX_OK;  // the mesh may be anywhere on screen: keep the natural order
+    }
+    for (size_t i = 0; i < c->spheres.size(); ++i) {
+        const Material &m = c->materials[c->sphere_mat[i]];
+        if (m.a2 == 0.0f && m.a3 == 0.0f) continue;
+        const float4 sp = c->spheres[i];
+        const float lo[3] = {sp.x - sp.w, sp.y - sp.w, sp.z - sp.w}, hi[3] = {sp.x + sp.w, sp.y + sp.w, sp.z + sp.w};
+        Rect r;
+        r.cls = 1;
+        if (projectBox(cam, f->width, f->height, lo, hi, r.r)) rects.push_back(r);
+    }
+    if (rects.empty()) return RTX_OK;
+    std::vector<unsigned> order[3];
+    for (int by = 0; by < blocks_y; ++by)
+        for (int bx = 0; bx < blocks_x; ++bx) {
+            const float c0 = (float)(bx * bt), c1 = (float)(bx * bt + bt - 1);
+            const float r0 = (float)(f->row_first + (long long)by * bt * f->row_step);
+            const float r1 = (float)(f->row_first + ((long long)by * bt + bt - 1) * f->row_step);
+            int cls = 2;
+            for (const Rect &r : rects)
+                if (c1 >= r.r[0] - 1 && c0 <= r.r[1] + 1 && r1 >= r.r[2] - 1 && r0 <= r.r[3] + 1 && r.cls < cls) cls = r.cls;
+            order[cls].push_back((unsigned)(by * blocks_x + bx));
+        }
+    std::vector<unsigned> all;
+    all.reserve(n);
+    for (auto &o : order) all.insert(all.end(), o.begin(), o.end());
+    if (n > c->d_order_cap) {
+        (void)hipFree(c->d_order);
+        c->d_order = nullptr, c->d_order_cap = 0;
+        HIP_OR_FAIL(hipMalloc((void **)&c->d_order, n * sizeof(unsigned)));
+        c->d_order_cap = n;
+    }
+    // The table may still be in use by an earlier launch on another stream: wait for the device.
+    HIP_OR_FAIL(hipDeviceSynchronize());
+    HIP_OR_FAIL(hipMemcpy(c->d_order, all.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
+    c->order_key = key;
+    *out = c->d_order;
+    return RTX_OK;
+}
+
 // enqueue one render on `stream`; output rows * width * 3 bytes at d_out
 int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
     const int rows = rtx_frame_rows(f);
     if (rows == 0) return RTX_OK;
     DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows};
-    const int tiles_x = (f->width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
-    const long long blocks = (long long)tiles_x * tiles_y;
+    const int variant = c->variant;  // experiment: bit0 = one wave per block, bits 1.. = wave tile 8/16/32
+    const int wt = ((variant >> 1) & 3) == 0 ? 8 : (((variant >> 1) & 3) == 1 ? 16 : 32);
+    const int threads = (variant & 1) ? 64 : kBlock;
+    const int bt = ((variant & 1) ? 1 : 2) * wt;
+    const int blocks_x = (f->width + bt - 1) / bt, blocks_y = (rows + bt - 1) / bt;
+    const long long blocks = (long long)blocks_x * blocks_y;
     if (blocks > 0x7fffffffLL) return fail(RTX_E_LIMIT, "frame too large for one launch");
     DevScene s = c->dev;
-    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    s.prune = c->prune | ((variant & 64) ? 2 : 0), s.far_clip = c->far_clip, s.fprec = c->fprec;
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
-    if (c->stats)
-        hipLaunchKernelGGL(k_render<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, tiles_x, d_out, c->d_counters);
-    else
-        hipLaunchKernelGGL(k_render<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, tiles_x, d_out, c->d_counters);
+    const unsigned *order = nullptr;
+    if (!(variant & 128))
+        if (int e = tileOrder(c, cam, f, bt, blocks_x, blocks_y, &order)) return e;
+#define RTX_LAUNCH(ST, WT) hipLaunchKernelGGL((k_render<ST, WT>), dim3((unsigned)blocks), dim3(threads), 0, stream, s, devCamera(cam), fr, blocks_x, order, d_out, c->d_counters)
+    if (c->stats) {
+        if (wt == 8) RTX_LAUNCH(true, 8); else if (wt == 16) RTX_LAUNCH(true, 16); else RTX_LAUNCH(true, 32);
+    } else {
+        if (wt == 8) RTX_LAUNCH(false, 8); else if (wt == 16) RTX_LAUNCH(false, 16); else RTX_LAUNCH(false, 32);
+    }
     HIP_OR_FAIL(hipGetLastError());
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -297,6 +473,7 @@ void rtx_destroy(rtx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_order);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -310,6 +487,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
     memcpy(&f, &value, 4);
     switch (option) {
         case RTX_OPT_STATS: c->stats = value != 0; break;
+        case 100: c->variant = (int)value; break;
         case RTX_OPT_PRUNE: c->prune = value != 0; break;
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
@@ -422,6 +600,10 @@ int rtx_commit(rtx_ctx *c) {
     if (c->committed) return fail(RTX_E_STATE, "already committed");
     if (c->sky_w == 0) return fail(RTX_E_STATE, "rtx_commit: no environment map (the reference cannot render without one)");
     if (c->materials.empty()) return fail(RTX_E_STATE, "rtx_commit: no materials");
+    if ((int)c->materials.size() > kMaxMaterials || (int)c->lights.size() > kMaxLights || (int)c->spheres.size() > kMaxSmallPrims ||
+        (int)c->tri_mat.size() > kMaxSmallPrims || (int)c->box_mat.size() > kMaxSmallPrims || (int)c->islands.size() > kMaxSmallPrims)
+        return fail(RTX_E_LIMIT, "rtx_commit: the analytic lists are staged in LDS: at most 32 materials, 8 lights and 16 spheres / "
+                                 "loose triangles / boxes / islands each (larger triangle sets belong in rtx_set_mesh)");
     if (int e = bind(c)) return e;
     DevScene &d = c->dev;
     memset(&d, 0, sizeof d);

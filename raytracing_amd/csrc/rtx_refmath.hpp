@@ -1,0 +1,173 @@
+// powf, acosf and atan2f with the bits the reference gets from its C library.
+//
+// The reference calls powf in the Phong term (src/Scene.cpp:78) and acos/atan2 -- both binding to
+// the float overloads -- in the sky lookup (src/SceneObjects.cpp:441-442).  A device math library
+// that is merely accurate differs from glibc in the last bit often enough to flip a colour level
+// or a texel here and there, so these three are restated from the algorithms glibc 2.35 uses on
+// x86-64 (the platform the reference frames were produced on) and checked against it on the CPU
+// over 10^9 inputs each (all 2.1e9 floats in [-1, 1] for acosf):
+//   - powf: the table-driven log2/exp2 scheme in double precision (16-entry log2 table, degree-4
+//     polynomial; 32-entry 2^(k/32) table, degree-3 polynomial).  glibc selects its FMA build of
+//     this routine on every CPU with FMA, so the polynomial steps below are explicit double fma();
+//   - acosf, atanf/atan2f: the classic fdlibm single-precision rational/polynomial kernels,
+//     evaluated in float without fusing.
+// Inputs outside what the trace loop produces (negative bases, NaN, infinities) take simplified
+// paths; the loop never passes them.
+#pragma once
+#include "rtx_device.hpp"
+
+namespace rtx {
+
+// x >= 0 (the caller tests specIntDot >= 0), y finite
+RTX_DEV float refPowf(const RefMathTables &T, float x, float y) {
+    unsigned ix = __float_as_uint(x);
+    if (y == 0.0f) return 1.0f;
+    if (ix == 0x3f800000u) return 1.0f;
+    if ((ix << 1) == 0u) return 0.0f;  // +-0 to a positive power
+    if (ix < 0x00800000u) {            // subnormal: scale up, fix the exponent
+        ix = __float_as_uint(x * 0x1p23f) & 0x7fffffffu;
+        ix -= 23u << 23;
+    }
+    // log2(x) = log2(z/c) + log2(c) + k with z in [0x1.66p-1, 0x1.66p0), c the sub-interval centre
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)(tmp >> 19) & 15;
+    const unsigned top = tmp & 0xff800000u;
+    const int k = (int)top >> 23;
+    const double invc = T.log2_tab[i][0], logc = T.log2_tab[i][1];
+    const double z = (double)__uint_as_float(ix - top);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double p0 = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p1 = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
+    q = __builtin_fma(p1, r2, q);
+    const double logx = __builtin_fma(p0, r4, q);
+    const double ylogx = (double)y * logx;
+    if (((unsigned)((unsigned long long)__double_as_longlong(ylogx) >> 47) & 0xffffu) >= (unsigned)(0x405f800000000000ull >> 47)) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return __uint_as_float(0x7f800000u);
+        if (ylogx <= -150.0) return 0.0f;
+    }
+    // 2^(ylogx) = 2^(k/32) * 2^r, k/32 obtained by the shift trick
+    const double shift = 0x1.8p+47;
+    double kd = ylogx + shift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= shift;
+    const double rr = ylogx - kd;
+    const unsigned long long t = T.exp2_tab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double rr2 = rr * rr;
+    double yy = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    yy = __builtin_fma(zz, rr2, yy);
+    return (float)(yy * s);
+}
+
+// fdlibm e_acosf
+RTX_DEV float refAcosf(float x) {
+    const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return __uint_as_float(0x7fc00000u);  // |x| > 1: NaN
+    if (ix < 0x3f000000) {                                     // |x| < 0.5
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {  // x < -0.5
+        const float z = (1.0f + x) * 0.5f;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float s = sqrtf(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (1.0f - x) * 0.5f;  // x > 0.5
+    const float s = sqrtf(z);
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+// fdlibm s_atanf
+RTX_DEV float refAtanf(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f,  -2.0000000298e-01f, 1.4285714924e-01f,  -1.1111110449e-01f,
+                          9.0908870101e-02f,  -7.6918758452e-02f, 6.6610731184e-02f,  -5.8335702866e-02f,
+                          4.9768779427e-02f,  -3.6531571299e-02f, 1.6285819933e-02f};
+    const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix >= 0x50800000) {  // |x| >= 2^34
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    int id;
+    float hi = 0.0f, lo = 0.0f;
+    if (ix < 0x3ee00000) {  // |x| < 0.4375
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) {
+                id = 0, hi = atanhi[0], lo = atanlo[0];
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1, hi = atanhi[1], lo = atanlo[1];
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000) {
+            id = 2, hi = atanhi[2], lo = atanlo[2];
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3, hi = atanhi[3], lo = atanlo[3];
+            x = -1.0f / x;
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+// fdlibm e_atan2f for finite arguments
+RTX_DEV float refAtan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = (int)__float_as_uint(x), hy = (int)__float_as_uint(y);
+    const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return refAtanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = refAtanf(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+}  // namespace rtx

@@ -2,6 +2,7 @@
 // lighting, the bounded per-lane ray stack that replaces traceRay's recursion, sky lookup.
 #pragma once
 #include "rtx_device.hpp"
+#include "rtx_refmath.hpp"
 
 namespace rtx {
 
@@ -122,7 +123,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
 // Returns `minDist < far_clip`; minDist itself comes back in min_dist.
 // ---------------------------------------------------------------------------------------------
 template <bool SHADOW, bool STATS>
-RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &min_dist, float t_exit, int *stack,
+RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, Hit &h, float &min_dist, float t_exit, int *stack,
                             int stride, LaneCounters<STATS> &lc) {
     float minDist = kFltMax;
     // what was hit last: 0 none, 1 sphere, 2 loose triangle, 3 box, 4 mesh triangle, 5 water, 6 island
@@ -133,7 +134,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     if (s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
         for (int i = 0; i < s.n_spheres; ++i) {
-            const float4 sp = s.spheres[i];
+            const float4 sp = q.spheres[i];
             float curDist = 0.0f;
             if (sphereHit(v3(sp.x, sp.y, sp.z), sp.w, orig, dir, curDist) && curDist < minDist) {
                 minDist = curDist;
@@ -149,7 +150,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     if (s.n_tris > 0 && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
         for (int i = 0; i < s.n_tris; ++i) {
-            const float *t = s.tris + 9 * i;
+            const float *t = q.tris + 9 * i;
             const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
             float curDist = 0.0f;
             if (triHit(v0, v1 - v0, v2 - v0, orig, dir, curDist) && curDist < minDist) {
@@ -161,7 +162,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     // cubesIntersect, :382-397
     if (s.n_boxes > 0 && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
         for (int i = 0; i < s.n_boxes; ++i) {
-            const float *b = s.boxes + 6 * i;
+            const float *b = q.boxes + 6 * i;
             const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
             if (!slabMaybe(lo, hi, orig, inv)) continue;
             RTX_COUNT(CNT_BOX_TESTS);
@@ -209,7 +210,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
             RTX_COUNT_N(CNT_ISLAND_TESTS, s.n_islands);
             const V3 pt = orig + dir * dist;
             for (int i = 0; i < s.n_islands; ++i) {
-                const float4 is = s.islands[i];  // cx, cz, a, b
+                const float4 is = q.islands[i];  // cx, cz, a, b
                 // the bounding-rectangle conditions come first in the reference's && chain as well; the
                 // two divisions of the ellipse test are only paid inside the rectangle
                 if (pt.x > is.x - is.z && pt.x < is.x + is.z && pt.z > is.y - is.w && pt.z < is.y + is.w && dist < minDist) {
@@ -231,19 +232,19 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
     h.point = orig + dir * minDist;
     int mat = 0;
     if (kind == 1) {
-        const float4 sp = s.spheres[index];
+        const float4 sp = q.spheres[index];
         h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
-        mat = s.sphere_mat[index];
+        mat = q.sphere_mat[index];
     } else if (kind == 2) {
-        const float *t = s.tris + 9 * index;
+        const float *t = q.tris + 9 * index;
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
         h.N = triNormal(v1 - v0, v2 - v0);
-        mat = s.tri_mat[index];
+        mat = q.tri_mat[index];
     } else if (kind == 3) {
-        const float *b = s.boxes + 6 * index;
+        const float *b = q.boxes + 6 * index;
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
         h.N = boxNormal(lo, hi, h.point);
-        mat = s.box_mat[index];
+        mat = q.box_mat[index];
     } else if (kind == 4) {
         const float4 *tp = s.mesh_tris + 3 * (size_t)index;
         const float4 p1 = tp[1], p2 = tp[2];
@@ -256,7 +257,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
         h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.island_mat;
     }
-    h.m = s.materials[mat];
+    h.m = q.materials[mat];
     if (kind == 5) {
         // texture tiles every `scale` units, nearest texel, blend (tex*0.3 + diffuse)/2: src/Scene.cpp:46-51
         float x = h.point.x / s.water_scale, z = h.point.z / s.water_scale;
@@ -293,8 +294,8 @@ RTX_DEV bool sceneIntersect(const DevScene &s, V3 orig, V3 dir, Hit &h, float &m
 // row shift wraps in uint32 before the modulo.  Texel = byte * (1/255.0f) (:429-434).
 RTX_DEV V3 skyColor(const DevScene &s, V3 dir) {
     const int width = s.sky_w, height = s.sky_h;
-    const float at = atan2f(dir.z, dir.x);
-    const float ac = acosf(dir.y);
+    const float at = refAtan2f(dir.z, dir.x);
+    const float ac = refAcosf(dir.y);
     int a = truncToIntD(((double)at / (2 * 3.14159265358979323846) + .5) * width);
     a = max(0, min(width - 1, a));
     int b = truncToIntD((double)ac / 3.14159265358979323846 * height);
@@ -308,12 +309,12 @@ RTX_DEV V3 skyColor(const DevScene &s, V3 dir) {
 
 // Scene::calcLightning, src/Scene.cpp:60-81
 template <bool STATS>
-RTX_DEV void calcLighting(const DevScene &s, V3 dir, V3 point, V3 N, float specular_exp, float &Ld, float &Ls,
+RTX_DEV void calcLighting(const DevScene &s, const SmallScene &q, V3 dir, V3 point, V3 N, float specular_exp, float &Ld, float &Ls,
                           int *stack, int stride, LaneCounters<STATS> &lc) {
     Ld = 0.0f, Ls = 0.0f;
     const V3 positiveOrig = point + N * s.fprec, negativeOrig = point - N * s.fprec;
     for (int i = 0; i < s.n_lights; ++i) {
-        const float4 L = s.lights[i];
+        const float4 L = q.lights[i];
         const V3 lpos = v3(L.x, L.y, L.z);
         const V3 lightDir = normalize(lpos - point);
         const float ndl = dot(lightDir, N);
@@ -326,7 +327,7 @@ RTX_DEV void calcLighting(const DevScene &s, V3 dir, V3 point, V3 N, float specu
         float minDist;
         RTX_COUNT(CNT_SHADOW);
         bool occluded = false;
-        if (sceneIntersect<true, STATS>(s, shadowOrig, lightDir, dummy, minDist, t_exit, stack, stride, lc)) {
+        if (sceneIntersect<true, STATS>(s, q, shadowOrig, lightDir, dummy, minDist, t_exit, stack, stride, lc)) {
             if (minDist < t_exit) {
                 occluded = true;
             } else {
@@ -338,7 +339,7 @@ RTX_DEV void calcLighting(const DevScene &s, V3 dir, V3 point, V3 N, float specu
         RTX_COUNT(CNT_LIT);
         if (ndl >= 0) Ld += L.w * ndl;
         const float specIntDot = dot(-reflect(-lightDir, N), dir);
-        if (specIntDot >= 0) Ls += powf(specIntDot, specular_exp) * L.w;
+        if (specIntDot >= 0) Ls += refPowf(q.math, specIntDot, specular_exp) * L.w;
     }
 }
 
@@ -354,89 +355,114 @@ struct Frame {
     V3 acc;          // partial sum so far
     float a2, a3;
     V3 rorig, rdir;  // pending refract ray
-    int state;       // bit0: waiting for reflect, bit1: refract still to do / waiting, bits 8..: depth of this node
+    int state;       // bit0: waiting for reflect, bit1: refract still to do, bit2: waiting for refract, bits 8..: depth of this node
 };
 
-template <bool STATS>
-RTX_DEV V3 traceRay(const DevScene &s, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
+// One path = one traceRay call tree, walked one node per step so that a wave can interleave the
+// paths of different pixels (lanes that finish take a new pixel while their neighbours go deeper).
+struct PathState {
+    V3 orig, dir;
+    int depth;      // remaining depth of the node to evaluate next
+    int fullDepth;  // depth of the root (statistics only)
+    int sp;         // frames in use
     Frame frames[kMaxDepth];
-    int sp = 0;
-    const int fullDepth = depth;
-    V3 color = v3(0, 0, 0);
-    for (;;) {
-        // ---- evaluate one node: (orig, dir, depth) ----
-        bool hit = false;
-        Hit h;
-        if (depth > 0) {
-            if constexpr (STATS) {
-                lc.v[depth == fullDepth ? CNT_PRIMARY : CNT_SECONDARY]++;
-            }
-            float md;
-            hit = sceneIntersect<false, STATS>(s, orig, dir, h, md, 0.0f, stack, stride, lc);
-        }
-        bool descended = false;
-        if (!hit) {
-            RTX_COUNT(CNT_SKY);
-            color = skyColor(s, dir);
+};
+
+RTX_DEV void pathStart(PathState &st, V3 orig, V3 dir, int depth) {
+    st.orig = orig, st.dir = dir, st.depth = depth, st.fullDepth = depth, st.sp = 0;
+}
+
+// Evaluates the next node of the path.  Returns true when the whole tree is done; `color` is then
+// the value traceRay would have returned.
+template <bool STATS>
+RTX_DEV bool pathStep(const DevScene &s, const SmallScene &q, PathState &st, V3 &color, int *stack, int stride, LaneCounters<STATS> &lc) {
+    const V3 orig = st.orig, dir = st.dir;
+    const int depth = st.depth;
+    bool hit = false;
+    Hit h;
+    if (depth > 0) {
+        if constexpr (STATS) lc.v[depth == st.fullDepth ? CNT_PRIMARY : CNT_SECONDARY]++;
+        float md;
+        hit = sceneIntersect<false, STATS>(s, q, orig, dir, h, md, 0.0f, stack, stride, lc);
+    }
+    if (!hit) {
+        RTX_COUNT(CNT_SKY);
+        color = skyColor(s, dir);
+    } else {
+        float Ld, Ls;
+        calcLighting<STATS>(s, q, dir, h.point, h.N, h.m.spec, Ld, Ls, stack, stride, lc);
+        const V3 base = v3(h.m.dr * Ld * h.m.a0, h.m.dg * Ld * h.m.a0, h.m.db * Ld * h.m.a0) +
+                        v3(Ls * h.m.a1, Ls * h.m.a1, Ls * h.m.a1);
+        const bool doRefl = !s.prune || h.m.a2 != 0.0f;
+        const bool doRefr = !s.prune || h.m.a3 != 0.0f;
+        if (!doRefl && !doRefr) {
+            color = base;
         } else {
-            float Ld, Ls;
-            calcLighting<STATS>(s, dir, h.point, h.N, h.m.spec, Ld, Ls, stack, stride, lc);
-            const V3 base = v3(h.m.dr * Ld * h.m.a0, h.m.dg * Ld * h.m.a0, h.m.db * Ld * h.m.a0) +
-                            v3(Ls * h.m.a1, Ls * h.m.a1, Ls * h.m.a1);
-            const bool doRefl = !s.prune || h.m.a2 != 0.0f;
-            const bool doRefr = !s.prune || h.m.a3 != 0.0f;
-            if (!doRefl && !doRefr) {
-                color = base;
+            const V3 positiveOrig = h.point + h.N * s.fprec, negativeOrig = h.point - h.N * s.fprec;
+            V3 reflD = v3(0, 0, 0), refrD = v3(0, 0, 0);
+            if (doRefl) reflD = normalize(reflect(dir, h.N));
+            if (doRefr) refrD = normalize(refractDir(dir, h.N, h.m.refractive));
+            if (depth == 1) {
+                // the children have depth 0: traceRay returns the sky colour of their direction at
+                // once (src/Scene.cpp:87-88), so they are evaluated in place
+                V3 c = base;
+                if (doRefl) {
+                    RTX_COUNT(CNT_SKY);
+                    c = c + skyColor(s, reflD) * h.m.a2;
+                }
+                if (doRefr) {
+                    RTX_COUNT(CNT_SKY);
+                    c = c + skyColor(s, refrD) * h.m.a3;
+                }
+                color = c;
             } else {
-                const V3 positiveOrig = h.point + h.N * s.fprec, negativeOrig = h.point - h.N * s.fprec;
                 Frame f;
                 f.acc = base;
                 f.a2 = h.m.a2, f.a3 = h.m.a3;
                 f.state = (doRefl ? 1 : 0) | (doRefr ? 2 : 0) | (depth << 8);
-                f.rorig = v3(0, 0, 0), f.rdir = v3(0, 0, 0);
-                if (doRefr) {
-                    const V3 rd = normalize(refractDir(dir, h.N, h.m.refractive));
-                    f.rdir = rd;
-                    f.rorig = __builtin_signbit(dot(rd, h.N)) ? negativeOrig : positiveOrig;
-                }
+                f.rdir = refrD;
+                f.rorig = __builtin_signbit(dot(refrD, h.N)) ? negativeOrig : positiveOrig;
                 if (doRefl) {
-                    const V3 rd = normalize(reflect(dir, h.N));
-                    orig = __builtin_signbit(dot(rd, h.N)) ? negativeOrig : positiveOrig;
-                    dir = rd;
+                    st.orig = __builtin_signbit(dot(reflD, h.N)) ? negativeOrig : positiveOrig;
+                    st.dir = reflD;
                 } else {
-                    orig = f.rorig, dir = f.rdir;
-                    f.state &= ~2;
-                    f.state |= 4;  // waiting for refract
+                    st.orig = f.rorig, st.dir = f.rdir;
+                    f.state = (f.state & ~2) | 4;
                 }
-                frames[sp++] = f;
-                depth -= 1;
-                descended = true;
+                st.frames[st.sp++] = f;
+                st.depth = depth - 1;
+                return false;
             }
         }
-        if (descended) continue;
-        // ---- return `color` to the waiting frames ----
-        bool resumed = false;
-        while (sp > 0) {
-            Frame &f = frames[sp - 1];
-            if (f.state & 1) {  // reflect child returned
-                f.acc = f.acc + color * f.a2;
-                f.state &= ~1;
-                if (f.state & 2) {  // now the refract child
-                    f.state &= ~2;
-                    f.state |= 4;
-                    orig = f.rorig, dir = f.rdir;
-                    depth = (f.state >> 8) - 1;
-                    resumed = true;
-                    break;
-                }
-                color = f.acc;
-                --sp;
-            } else {  // refract child returned
-                color = f.acc + color * f.a3;
-                --sp;
+    }
+    // ---- return `color` to the waiting frames ----
+    while (st.sp > 0) {
+        Frame &f = st.frames[st.sp - 1];
+        if (f.state & 1) {  // reflect child returned
+            f.acc = f.acc + color * f.a2;
+            f.state &= ~1;
+            if (f.state & 2) {  // now the refract child
+                f.state = (f.state & ~2) | 4;
+                st.orig = f.rorig, st.dir = f.rdir;
+                st.depth = (f.state >> 8) - 1;
+                return false;
             }
+            color = f.acc;
+            --st.sp;
+        } else {  // refract child returned
+            color = f.acc + color * f.a3;
+            --st.sp;
         }
-        if (!resumed) break;
+    }
+    return true;
+}
+
+template <bool STATS>
+RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
+    PathState st;
+    pathStart(st, orig, dir, depth);
+    V3 color = v3(0, 0, 0);
+    while (!pathStep<STATS>(s, q, st, color, stack, stride, lc)) {
     }
     return color;
 }
