@@ -94,7 +94,12 @@ enum rtx_option {
     RTX_OPT_PRUNE = 2,        /* 0/1 (default 1): skip children whose albedo weight is exactly 0;
                                  the reference traces them and multiplies by 0 (src/Scene.cpp:95-105) */
     RTX_OPT_FAR_CLIP = 3,     /* float bits: sceneIntersect's `minDist < 700` (src/Scene.cpp:57)   */
-    RTX_OPT_SURFACE_BIAS = 4  /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
+    RTX_OPT_SURFACE_BIAS = 4, /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
+    RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
+                                 by rays that pass one of the 7x7x7 grid cells holding its vertices,
+                                 as the reference's BoundingBox walk has it (src/SceneObjects.cpp:
+                                 176-209, 350-380; large triangles have holes); 0 = every triangle
+                                 is tested for every ray (watertight mesh)                          */
 };
 
 const char *rtx_last_error(void);

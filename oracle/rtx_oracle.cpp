@@ -261,6 +261,7 @@ struct rtx_ctx {
     bool count = false;
     bool prune = false;  // the oracle follows the reference and traces zero-weight children
     float far_clip = 700.0f;
+    bool mesh_grid = true;
     float fprec = 0.001f;
     Stats stats;
     double last_ms = 0;
@@ -296,7 +297,20 @@ void meshIntersect(rtx_ctx &s, V3 orig, V3 dir, Hit &h, float &minDist, Stats *s
     if (s.has_mesh) {
         const Grid &g = *s.grid;
         float nearDist = 0, farDist = 0;
-        if (boxSlab(g.box, orig, dir, nearDist, farDist)) {
+        if (boxSlab(g.box, orig, dir, nearDist, farDist) && !s.mesh_grid) {
+            // RTX_OPT_MESH_GRID = 0: every triangle is a candidate, in index order
+            if (st) st->box_hits++;
+            float curDist = 0.0f;
+            for (const Tri &t : s.mesh) {
+                if (st) st->tri_tests++;
+                if (triHit(t, orig, dir, curDist) && curDist < modelsDist && curDist < minDist) {
+                    modelsDist = curDist;
+                    h.point = orig + dir * curDist;
+                    h.N = triangleNormal(t.v0, t.v1, t.v2);
+                    h.m = s.materials[t.mat];
+                }
+            }
+        } else if (boxSlab(g.box, orig, dir, nearDist, farDist)) {
             if (st) st->box_hits++;
             for (int i = 0; i < Grid::size; i++)
                 for (int j = 0; j < Grid::size; j++)
@@ -558,6 +572,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_PRUNE: c->prune = value != 0; break;
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
+        case RTX_OPT_MESH_GRID: c->mesh_grid = value != 0; break;
         default: return fail(RTX_E_INVALID, "unknown option");
     }
     return RTX_OK;

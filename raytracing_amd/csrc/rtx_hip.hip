@@ -270,6 +270,7 @@ struct rtx_ctx {
     bool stats = false;
     int variant = 0;
     int prune = 1;
+    int mesh_grid = 1;
     float far_clip = 700.0f, fprec = 0.001f;
     // device state
     bool committed = false;
@@ -290,6 +291,45 @@ namespace {
 int bind(rtx_ctx *c) {
     HIP_OR_FAIL(hipSetDevice(c->device));
     return RTX_OK;
+}
+
+// BoundingBox::init + initTriangles, src/SceneObjects.cpp:176-209: the 7x7x7 cells of the padded
+// vertex bounds and, per triangle, the cells its vertices fall into.  cells = lo xyz, hi xyz per
+// cell in i,j,k order; keys = four ints per triangle: (cell << 22 | position in that cell's list)
+// for each distinct cell, -1 for unused slots.  Arithmetic as the reference writes it (binary32,
+// no contraction), so that a vertex on a cell boundary lands in the same cell.
+void gridCells(const std::vector<float> &verts, const std::vector<int> &idx, const float lo[3], const float hi[3],
+               std::vector<float> &cells, std::vector<int> &keys) {
+    const int size = 7;
+    const float lx = hi[0] - lo[0], ly = hi[1] - lo[1], lz = hi[2] - lo[2];
+    const float px = lx / float(size), py = ly / float(size), pz = lz / float(size);
+    cells.resize((size_t)size * size * size * 6);
+    for (int i = 0; i < size; ++i)
+        for (int j = 0; j < size; ++j)
+            for (int k = 0; k < size; ++k) {
+                const float a[3] = {lo[0] + px * i, lo[1] + py * j, lo[2] + pz * k};
+                const float b[3] = {lo[0] + px * (i + 1), lo[1] + py * (j + 1), lo[2] + pz * (k + 1)};
+                float *c = &cells[(size_t)((i * size + j) * size + k) * 6];
+                for (int t = 0; t < 3; ++t) c[t] = a[t] < b[t] ? a[t] : b[t], c[3 + t] = a[t] < b[t] ? b[t] : a[t];  // Cube::load
+            }
+    const size_t nt = idx.size() / 3;
+    keys.assign(nt * 4, -1);
+    std::vector<int> fill((size_t)size * size * size, 0);
+    for (size_t ti = 0; ti < nt; ++ti) {
+        int used = 0;
+        for (int v = 0; v < 3; ++v) {
+            const float *p = &verts[3 * (size_t)idx[3 * ti + v]];
+            const float fx = (p[0] - lo[0]) * size / lx, fy = (p[1] - lo[1]) * size / ly, fz = (p[2] - lo[2]) * size / lz;
+            const int i = int(fx), j = int(fy), k = int(fz);
+            if (i < 0 || j < 0 || k < 0 || i >= size || j >= size || k >= size) continue;  // outside: in no cell
+            const int cell = (i * size + j) * size + k;
+            bool seen = false;
+            for (int u = 0; u < used; ++u) seen |= (keys[4 * ti + u] >> 22) == cell;
+            if (seen) continue;
+            const int pos = fill[cell]++;
+            keys[4 * ti + used++] = (cell << 22) | (pos < (1 << 22) ? pos : (1 << 22) - 1);
+        }
+    }
 }
 
 int checkMat(const rtx_ctx *c, const int *mat, int n) {
@@ -491,6 +531,10 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_PRUNE: c->prune = value != 0; break;
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
+        case RTX_OPT_MESH_GRID:
+            if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_MESH_GRID must be set before rtx_commit");
+            c->mesh_grid = value != 0;
+            break;
         default: return fail(RTX_E_INVALID, "unknown option");
     }
     return RTX_OK;
@@ -693,6 +737,17 @@ int rtx_commit(rtx_ctx *c) {
         }
         c->bvh_depth = r.max_depth;
         d.mesh_tris = r.tris, d.bvh = r.nodes, d.n_mesh_tris = nt, d.mesh_mat = c->mesh_mat;
+        d.mesh_cells = nullptr, d.grid_cells = nullptr;
+        if (c->mesh_grid) {
+            std::vector<float> cells;
+            std::vector<int> keys;
+            gridCells(c->mesh_verts, c->mesh_idx, d.mesh_lo, d.mesh_hi, cells, keys);
+            float *dc;
+            int *dk;
+            if (int e = upload(cells, &dc, c->owned)) return e;
+            if (int e = upload(keys, &dk, c->owned)) return e;
+            d.grid_cells = dc, d.mesh_cells = reinterpret_cast<const int4 *>(dk);
+        }
     }
     c->committed = true;
     // host copies are no longer needed

@@ -45,6 +45,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
     const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
     int sp = 0;
     int node = 0;
+    int best_key = 0x7fffffff;  // order in which the reference's cell walk reaches best_tri
     for (;;) {
         const float4 *np = reinterpret_cast<const float4 *>(s.bvh + node);
         const float4 a = np[0], b = np[1], c = np[2];
@@ -82,10 +83,31 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                 const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
                                        STATS ? &past_u : nullptr);
                 if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
-                if (th && t < best_t) {
-                    best_t = t;
-                    best_tri = ti;
-                    if (SHADOW && t < t_exit) return true;
+                if (th && t <= best_t) {
+                    // of two hits at the same distance the reference keeps the one it tests first
+                    int key = ti;
+                    if (s.mesh_cells) {
+                        // the triangle exists for this ray only if the ray passes a cell holding one
+                        // of its vertices; the i,j,k cell walk reaches it in the order of the keys
+                        const int4 keys = s.mesh_cells[ti];
+                        key = 0x7fffffff;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
+                            if (k < 0 || k >= key) continue;
+                            const float *cb = s.grid_cells + 6 * (k >> 22);
+                            const float lo[3] = {cb[0], cb[1], cb[2]}, hi[3] = {cb[3], cb[4], cb[5]};
+                            float cell_near = 0.0f;
+                            if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
+                        }
+                    }
+                    const bool take = key != 0x7fffffff && (t < best_t || (best_tri >= 0 && key < best_key));
+                    if (take) best_key = key;
+                    if (take) {
+                        best_t = t;
+                        best_tri = ti;
+                        if (SHADOW && t < t_exit) return true;
+                    }
                 }
             }
         }
