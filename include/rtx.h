@@ -85,7 +85,10 @@ typedef struct rtx_stats {
     uint64_t plane_tests;     /* ray/plane tests (water plane, island plane)                   */
     uint64_t island_tests;    /* ellipse containment tests                                     */
     uint64_t lit_lights;      /* light evaluations that were not in shadow (Phong + powf)      */
-    uint64_t reserved[2];
+    uint64_t node_wave_trips; /* HIP backend: trips of the node loop counted once per wavefront; 64 x
+                                 this / bvh_node_tests = how many lane slots each useful node test
+                                 costs (SIMT divergence of the mesh walk); 0 on the oracle       */
+    uint64_t tri_wave_trips;  /* the same for the triangle test of the mesh walk               */
     double kernel_ms;         /* device time of the trace kernel(s), HIP events                */
 } rtx_stats;
 
@@ -95,6 +98,10 @@ enum rtx_option {
                                  the reference traces them and multiplies by 0 (src/Scene.cpp:95-105) */
     RTX_OPT_FAR_CLIP = 3,     /* float bits: sceneIntersect's `minDist < 700` (src/Scene.cpp:57)   */
     RTX_OPT_SURFACE_BIAS = 4, /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
+    RTX_OPT_BVH_BUILDER = 6,  /* before rtx_commit: 0 (default) = surface-area heuristic on the host
+                                 for meshes up to 262 144 triangles, Morton order on the GPU above;
+                                 1 = always Morton order on the GPU; 2 = always surface-area
+                                 heuristic.  The tree only steers the walk: results do not change */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:

@@ -12,6 +12,14 @@
 
 namespace rtx {
 
+// Triangle boxes are padded so that the box test, done with reciprocals and FMA, can never cull a
+// triangle the exact float test accepts: the rounding of (b - o) * (1/d) is a few ulp of the
+// coordinates involved, far below this.
+constexpr float kBvhPad = 2e-5f;
+// rtx_commit builds meshes up to this many triangles with the surface-area heuristic on the host
+// (sah_build.hpp) unless told otherwise; larger ones keep the tree built here.
+constexpr int kSahAutoMaxTris = 1 << 18;
+
 struct Aabb {
     float lo[3], hi[3];
 };
@@ -265,10 +273,7 @@ inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, hipS
     float4 *tris = nullptr;
     BvhNode *nodes = nullptr;
     const int n_inner = nt > 1 ? nt - 1 : 1;
-    // Boxes are padded so that the box test, done with reciprocals and FMA, can never cull a
-    // triangle the exact float test accepts: the rounding of (b - o) * (1/d) is a few ulp of the
-    // coordinates involved, far below this.
-    const float pad = 2e-5f;
+    const float pad = kBvhPad;
     unsigned init_bounds[6];
     {
         const float big = kFltMax;

@@ -151,7 +151,7 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
 // Statistics slots, in the order of rtx_stats' 64-bit fields (include/rtx.h).
 enum CounterSlot {
     CNT_PRIMARY, CNT_SECONDARY, CNT_SHADOW, CNT_SKY, CNT_BOX_HITS, CNT_NODE_TESTS, CNT_TRI_TESTS, CNT_TRI_FULL,
-    CNT_SPHERE_TESTS, CNT_LOOSE_TRI_TESTS, CNT_BOX_TESTS, CNT_PLANE_TESTS, CNT_ISLAND_TESTS, CNT_LIT, CNT_SLOTS = 16
+    CNT_SPHERE_TESTS, CNT_LOOSE_TRI_TESTS, CNT_BOX_TESTS, CNT_PLANE_TESTS, CNT_ISLAND_TESTS, CNT_LIT, CNT_NODE_TRIPS, CNT_TRI_TRIPS, CNT_SLOTS = 16
 };
 struct Counters {
     unsigned long long v[CNT_SLOTS];

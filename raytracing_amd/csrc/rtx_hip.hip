@@ -14,6 +14,7 @@
 
 #include "../../include/rtx.h"
 #include "lbvh_build.hpp"
+#include "sah_build.hpp"
 #include "rtx_device.hpp"
 #include "rtx_trace.hpp"
 
@@ -62,87 +63,85 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
     }
 }
 
-// Lane refill inside a wave-owned tile.  A block covers a 32x32-pixel area, each of its four waves
-// a 16x16 quadrant, i.e. a pool of 256 pixel slots (four 8x8 chunks).  Every trip of the loop
-// evaluates one node of each active lane's path (closest hit + shadow rays + shading); a lane whose
-// path is complete writes its pixel and takes the next slot of the wave's pool at the top of the
-// next trip, so lanes that finish early (sky, diffuse surfaces) do not idle while neighbours bounce
-// through glass.  Idle lanes get consecutive slots in lane order (ballot + mbcnt), which keeps the
-// rays of a refill batch adjacent on screen.  The wave leaves when its pool is empty and all lanes
-// are idle; blocks are balanced over the chip by the hardware dispatcher (no global work counter:
-// device-scope atomics on one address serialise at about 10 ns each, far too slow at one per chunk).
-template <bool STATS, int kWaveTile>
-__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, int blocks_x,
-                                                   const unsigned *__restrict__ order,
+// Work distribution.  The frame is cut into 8x8-pixel tiles, listed in `order` (expensive ones
+// first, see tileOrder) and dealt round-robin into kQueues queues: queue k owns entries k,
+// k + kQueues, ...  Each queue has a head counter in a cache line of its own.  The grid is sized to
+// fill the chip once; every WAVE then works on its own: it takes a tile from its queue (one atomic
+// per 64 pixels, on one of kQueues addresses -- atomics on a single address serialise at about
+// 10 ns each, far too slow for 130 000 tiles per 4K frame), and when that queue is empty it looks at
+// all heads at once (one per lane) and moves to the next queue that still has entries.  No wave
+// slot ever waits for the slowest wave of a block, and no block pays the LDS staging twice.
+//
+// Inside the wave each lane owns one pixel of the tile and advances its path by ONE RAY per trip of
+// the loop (closest-hit or shadow ray, see pathConsume), so a lane whose ray left the scene goes on
+// with its next ray while its neighbours cast shadow rays.  A tile stays with its wave until all 64
+// paths are complete: handing finished lanes pixels of the next tile keeps more lanes busy, but
+// mixes rays of different screen regions in one wave, and the loss of coherence (more divergent
+// category tests, longer mesh walks) costs more than the idle lanes do.
+constexpr unsigned kQueues = 64, kHeadStride = 32;
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
+                                                   const unsigned *__restrict__ order, unsigned *heads,
                                                    unsigned char *__restrict__ out, Counters *counters) {
-    constexpr unsigned kWaveSlots = kWaveTile * kWaveTile;
-    constexpr int kChunksX = kWaveTile / 8;
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     loadSmallScene(q, s);
     __syncthreads();
-    const int wave = threadIdx.x >> 6;
     int *stack = s_stack + threadIdx.x;
-    const int wpb = blockDim.x >> 6;  // waves per block: 1 or 4
-    const int bt = (wpb == 4 ? 2 : 1) * kWaveTile;
-    // Blocks are dispatched in blockIdx order; `order` lists the tiles with the expensive ones first
-    // (see tileOrder), so the longest-running waves start at once instead of in the middle of the frame.
-    const unsigned tile = order ? order[blockIdx.x] : blockIdx.x;
-    const int x0 = (int)(tile % (unsigned)blocks_x) * bt + (wave & 1) * kWaveTile;
-    const int y0 = (int)(tile / (unsigned)blocks_x) * bt + (wave >> 1) * kWaveTile;
+    const unsigned lane = threadIdx.x & 63u;
+    static_assert(kQueues == 64, "one queue head per lane in the scan below");
+    const unsigned my_len = lane < n_tiles ? (n_tiles - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
+    unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
     LaneCounters<STATS> lc;
-    unsigned long long t_begin = 0;
-    if (STATS || (s.prune & 2)) t_begin = __builtin_amdgcn_s_memrealtime();
     PathState st;
-    bool active = false;
-    int px = 0, pk = 0;
-    unsigned next_slot = 0;  // wave-uniform: first unassigned slot of the pool
+    Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (idle && next_slot < kWaveSlots) {
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-            const unsigned slot = next_slot + rank;
-            if (!active && slot < kWaveSlots) {
-                const unsigned chunk = slot >> 6, pos = slot & 63u;
-                px = x0 + (int)(chunk % kChunksX) * 8 + (int)(pos & 7u);
-                pk = y0 + (int)(chunk / kChunksX) * 8 + (int)(pos >> 3);
-                if (px < fr.width && pk < fr.rows) {
-                    const int row = fr.row_first + pk * fr.row_step;
-                    pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
-                    active = true;
-                }
+        // ---- take a tile ----
+        unsigned tile = 0xffffffffu;
+        for (;;) {
+            const unsigned len = __builtin_amdgcn_readlane(my_len, qi);
+            unsigned i = len;
+            if (lane == 0 && len) i = atomicAdd(heads + qi * kHeadStride, 1u);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i < len) {
+                const unsigned e = qi + i * kQueues;
+                tile = order ? order[e] : e;
+                break;
             }
-            next_slot += (unsigned)__popcll(idle);
+            // this queue is empty: every lane looks at one head, the wave moves to the next queue
+            // (cyclically after qi) that still has entries, or leaves when there is none
+            const unsigned head = __hip_atomic_load(heads + lane * kHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long live = __ballot(head < my_len);
+            live &= ~(1ull << qi);
+            if (!live) break;
+            const unsigned long long after = qi == 63u ? 0ull : live & (~0ull << (qi + 1u));
+            qi = (unsigned)__builtin_ctzll(after ? after : live);
         }
-        if (!__any(active)) {
-            if (next_slot >= kWaveSlots) break;
-            continue;  // the slots handed out lay outside the frame: take the next ones
-        }
+        if (tile == 0xffffffffu) break;  // every queue is empty
+        const int px = (int)(tile % tiles_x) * 8 + (int)(lane & 7u);
+        const int pk = (int)(tile / tiles_x) * 8 + (int)(lane >> 3);
+        bool active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
         if (active) {
+            const int row = fr.row_first + pk * fr.row_step;
+            pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
+        }
+        // ---- trace its 64 paths ----
+        while (active) {
+            bool hit = false;
+            Hit h;
+            float md = 0.0f;
+            if (pathCasts(st)) {
+                pathCountRay<STATS>(st, lc);
+                hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
+            }
             V3 c;
-            if (pathStep<STATS>(s, q, st, c, stack, blockDim.x, lc)) {
+            if (pathConsume<STATS>(s, q, st, frames, hit, h, md, c, lc)) {
                 unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
                 p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
                 active = false;
             }
-        }
-    }
-    if constexpr (STATS) {
-        // wave lifetime in 100 MHz ticks: slot 14 = longest wave, slot 15 = sum over waves
-        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_begin;
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(&counters->v[14], dt);
-            atomicAdd(&counters->v[15], dt);
-        }
-    }
-    if (s.prune & 2) {  // debug: paint the wave's lifetime (in units of 0.25 us) over its tile
-        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_begin;
-        const unsigned v = (unsigned)min(dt / 25ull, 65535ull);
-        const int lx = x0 + (int)(threadIdx.x & 7), ly = y0 + (int)((threadIdx.x & 63) >> 3);
-        if (kWaveTile == 8 && lx < fr.width && ly < fr.rows) {
-            unsigned char *p = out + ((size_t)ly * fr.width + lx) * 3;
-            p[0] = (unsigned char)(v & 255), p[1] = (unsigned char)(v >> 8), p[2] = 0;
         }
     }
     flushCounters<STATS>(lc, counters);
@@ -177,9 +176,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const flo
     h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
     h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
     float md;
-    const bool ok = sceneIntersect<false, false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
-                                                 v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), h, md, 0.0f,
-                                                 s_stack + threadIdx.x, kBlock, lc);
+    const bool ok = sceneIntersect<false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+                                          v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md,
+                                          s_stack + threadIdx.x, kBlock, lc);
     float *o = out16 + 16 * (size_t)i;
     o[0] = ok ? 1.0f : 0.0f;
     o[1] = h.point.x, o[2] = h.point.y, o[3] = h.point.z;
@@ -268,9 +267,9 @@ struct rtx_ctx {
     int sky_w = 0, sky_h = 0, sky_shift = 100;
     // options
     bool stats = false;
-    int variant = 0;
     int prune = 1;
     int mesh_grid = 1;
+    int bvh_builder = 0;  // RTX_OPT_BVH_BUILDER
     float far_clip = 700.0f, fprec = 0.001f;
     // device state
     bool committed = false;
@@ -278,6 +277,8 @@ struct rtx_ctx {
     std::vector<void *> owned;
     int bvh_depth = 0;
     Counters *d_counters = nullptr;
+    unsigned *d_heads = nullptr;      // work-queue heads of k_render
+    int resident_blocks[2] = {0, 0};  // grid size of k_render<false> / <true>
     // launch order of the tiles, cached for the last (camera, frame, tile size) it was built for
     unsigned *d_order = nullptr;
     size_t d_order_cap = 0;
@@ -449,31 +450,40 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
     return RTX_OK;
 }
 
-// enqueue one render on `stream`; output rows * width * 3 bytes at d_out
+// enqueue one render on `stream`; output rows * width * 3 bytes at d_out.  The queue heads, the
+// counters and the timing events belong to the context: one render of a context at a time.
 int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
     const int rows = rtx_frame_rows(f);
     if (rows == 0) return RTX_OK;
     DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows};
-    const int variant = c->variant;  // experiment: bit0 = one wave per block, bits 1.. = wave tile 8/16/32
-    const int wt = ((variant >> 1) & 3) == 0 ? 8 : (((variant >> 1) & 3) == 1 ? 16 : 32);
-    const int threads = (variant & 1) ? 64 : kBlock;
-    const int bt = ((variant & 1) ? 1 : 2) * wt;
-    const int blocks_x = (f->width + bt - 1) / bt, blocks_y = (rows + bt - 1) / bt;
-    const long long blocks = (long long)blocks_x * blocks_y;
-    if (blocks > 0x7fffffffLL) return fail(RTX_E_LIMIT, "frame too large for one launch");
+    const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
+    const long long n_tiles = (long long)tiles_x * tiles_y;
+    if (n_tiles > 0x7fffffffLL) return fail(RTX_E_LIMIT, "frame too large for one launch");
     DevScene s = c->dev;
-    s.prune = c->prune | ((variant & 64) ? 2 : 0), s.far_clip = c->far_clip, s.fprec = c->fprec;
-    if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
-    HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
+    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
     const unsigned *order = nullptr;
-    if (!(variant & 128))
-        if (int e = tileOrder(c, cam, f, bt, blocks_x, blocks_y, &order)) return e;
-#define RTX_LAUNCH(ST, WT) hipLaunchKernelGGL((k_render<ST, WT>), dim3((unsigned)blocks), dim3(threads), 0, stream, s, devCamera(cam), fr, blocks_x, order, d_out, c->d_counters)
-    if (c->stats) {
-        if (wt == 8) RTX_LAUNCH(true, 8); else if (wt == 16) RTX_LAUNCH(true, 16); else RTX_LAUNCH(true, 32);
-    } else {
-        if (wt == 8) RTX_LAUNCH(false, 8); else if (wt == 16) RTX_LAUNCH(false, 16); else RTX_LAUNCH(false, 32);
+    if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order)) return e;
+    // blocks that are resident at once: the kernel is a loop over tiles, more blocks would only queue
+    int &resident = c->resident_blocks[c->stats ? 1 : 0];
+    if (resident == 0) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
+        if (c->stats) HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<true>, kBlock, 0));
+        else HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<false>, kBlock, 0));
+        resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
     }
+    const long long want = (n_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned blocks = (unsigned)(want < resident ? want : resident);
+    HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
+    if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
+    HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
+    if (c->stats)
+        hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
+                           (unsigned)n_tiles, order, c->d_heads, d_out, c->d_counters);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
+                           (unsigned)n_tiles, order, c->d_heads, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -499,7 +509,8 @@ int rtx_create(rtx_ctx **out, int device_id) {
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess) {
+        (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_heads, kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess) {
         delete c;
         return failHip(e, "rtx_create");
     }
@@ -513,6 +524,7 @@ void rtx_destroy(rtx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_heads);
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -527,10 +539,14 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
     memcpy(&f, &value, 4);
     switch (option) {
         case RTX_OPT_STATS: c->stats = value != 0; break;
-        case 100: c->variant = (int)value; break;
         case RTX_OPT_PRUNE: c->prune = value != 0; break;
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
+        case RTX_OPT_BVH_BUILDER:
+            if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
+            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 auto, 1 Morton order on the GPU, 2 surface-area heuristic on the host");
+            c->bvh_builder = (int)value;
+            break;
         case RTX_OPT_MESH_GRID:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_MESH_GRID must be set before rtx_commit");
             c->mesh_grid = value != 0;
@@ -730,6 +746,14 @@ int rtx_commit(rtx_ctx *c) {
         hipError_t he = lbvhBuild(dv, di, nt, c->stream, &r);
         if (he != hipSuccess) return failHip(he, "LBVH build");
         c->owned.push_back(r.tris), c->owned.push_back(r.nodes);
+        // Small meshes get the better tree; the triangle array of the GPU build is kept either way.
+        const bool sah = c->bvh_builder == 2 || (c->bvh_builder == 0 && nt <= kSahAutoMaxTris);
+        if (sah) {
+            std::vector<BvhNode> nodes;
+            SahBuilder builder(c->mesh_verts, c->mesh_idx, kBvhPad);
+            r.max_depth = builder.build(nodes, kStackDepth);
+            HIP_OR_FAIL(hipMemcpy(r.nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+        }
         if (r.max_depth > kStackDepth) {
             char msg[160];
             snprintf(msg, sizeof msg, "LBVH depth %d exceeds the traversal stack (%d entries)", r.max_depth, kStackDepth);

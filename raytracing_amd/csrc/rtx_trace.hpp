@@ -15,6 +15,13 @@ struct LaneCounters {
 template <>
 struct LaneCounters<false> {};
 
+// true in exactly one of the lanes that execute the call together
+RTX_DEV bool firstActiveLane() {
+    const unsigned long long m = __ballot(1);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(0xffffffffu, __builtin_amdgcn_mbcnt_lo(0xffffffffu, 0u));
+    return lane == (unsigned)__builtin_ctzll(m);
+}
+
 #define RTX_COUNT(slot) \
     if constexpr (STATS) lc.v[slot]++
 #define RTX_COUNT_N(slot, n) \
@@ -25,130 +32,141 @@ struct LaneCounters<false> {};
 // t < best_t (strict, as modelsIntersect's `curDist < modelsDist && curDist < minDist`,
 // src/SceneObjects.cpp:365-366).  `stack` points at this lane's column of an LDS array whose rows
 // are `stride` ints apart, so the 64 lanes of a wave hit 64 different banks.
-// In SHADOW mode the walk stops at the first hit nearer than t_exit.
+// The walk stops at the first hit nearer than t_exit (shadow rays; closest-hit rays pass a
+// negative t_exit) and then returns true.
 // ---------------------------------------------------------------------------------------------
-template <bool SHADOW, bool STATS>
-RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
-                           int *stack, int stride, LaneCounters<STATS> &lc) {
-    // the gate: Model::boxIntersect on the padded vertex bounds, src/SceneObjects.cpp:356 -- the
-    // cheap filter first, the reference's own slab test (six IEEE divisions) only for candidates
+// The gate of the mesh: Model::boxIntersect on the padded vertex bounds, src/SceneObjects.cpp:356 --
+// the cheap filter first, the reference's own slab test (six IEEE divisions) only for candidates.
+template <bool STATS>
+RTX_DEV bool meshGate(const DevScene &s, V3 orig, V3 dir, V3 inv, LaneCounters<STATS> &lc) {
     if (!slabMaybe(s.mesh_lo, s.mesh_hi, orig, inv)) return false;
     RTX_COUNT(CNT_BOX_TESTS);
     float gate_near = 0.0f;
     if (!boxSlab(s.mesh_lo, s.mesh_hi, orig, dir, gate_near)) return false;
     RTX_COUNT(CNT_BOX_HITS);
+    return true;
+}
 
+template <bool STATS>
+RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
+                           int *stack, int stride, LaneCounters<STATS> &lc) {
     // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
     // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
     // accept is never culled by rounding here.
     const float ix = inv.x, iy = inv.y, iz = inv.z;  // clamped reciprocals: no inf - inf below
     const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
+    // Two alternating phases, each a loop the whole wave runs together: descend through inner
+    // nodes until this lane holds a leaf (lanes that found theirs idle until the rest have), then
+    // one triangle test for every lane that holds one.  `cur` >= 0 is an inner node, < 0 is leaf
+    // ~cur, kDone means the stack ran dry.  A single-triangle mesh has an inner root with one leaf.
+    constexpr int kDone = (int)0x80000000;
     int sp = 0;
-    int node = 0;
-    int best_key = 0x7fffffff;  // order in which the reference's cell walk reaches best_tri
+    int cur = 0;
+    int best_key = 0x7fffffff;  // order in which the reference's walk reaches best_tri
     for (;;) {
-        const float4 *np = reinterpret_cast<const float4 *>(s.bvh + node);
-        const float4 a = np[0], b = np[1], c = np[2];
-        const int4 ch = *reinterpret_cast<const int4 *>(np + 3);
-        RTX_COUNT(CNT_NODE_TESTS);
-        float tnL, tfL, tnR, tfR;
-        {
-            float t0 = __builtin_fmaf(a.x, ix, ox), t1 = __builtin_fmaf(a.w, ix, ox);
-            float t2 = __builtin_fmaf(a.y, iy, oy), t3 = __builtin_fmaf(b.x, iy, oy);
-            float t4 = __builtin_fmaf(a.z, iz, oz), t5 = __builtin_fmaf(b.y, iz, oz);
-            tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-            tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+        while (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(s.bvh + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+            RTX_COUNT(CNT_NODE_TESTS);
+            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
+            float tnL, tfL, tnR, tfR;
+            {
+                float t0 = __builtin_fmaf(a.x, ix, ox), t1 = __builtin_fmaf(a.w, ix, ox);
+                float t2 = __builtin_fmaf(a.y, iy, oy), t3 = __builtin_fmaf(b.x, iy, oy);
+                float t4 = __builtin_fmaf(a.z, iz, oz), t5 = __builtin_fmaf(b.y, iz, oz);
+                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+            }
+            {
+                float t0 = __builtin_fmaf(b.z, ix, ox), t1 = __builtin_fmaf(c.y, ix, ox);
+                float t2 = __builtin_fmaf(b.w, iy, oy), t3 = __builtin_fmaf(c.z, iy, oy);
+                float t4 = __builtin_fmaf(c.x, iz, oz), t5 = __builtin_fmaf(c.w, iz, oz);
+                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+            }
+            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
+            if (hitL && hitR) {
+                const bool leftFirst = tnL <= tnR;
+                stack[sp * stride] = leftFirst ? ch.y : ch.x;
+                ++sp;
+                cur = leftFirst ? ch.x : ch.y;
+            } else if (hitL || hitR) {
+                cur = hitL ? ch.x : ch.y;
+            } else if (sp > 0) {
+                --sp;
+                cur = stack[sp * stride];
+            } else {
+                cur = kDone;
+            }
         }
+        if (cur == kDone) break;
         {
-            float t0 = __builtin_fmaf(b.z, ix, ox), t1 = __builtin_fmaf(c.y, ix, ox);
-            float t2 = __builtin_fmaf(b.w, iy, oy), t3 = __builtin_fmaf(c.z, iy, oy);
-            float t4 = __builtin_fmaf(c.x, iz, oz), t5 = __builtin_fmaf(c.w, iz, oz);
-            tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-            tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
-        }
-        bool hitL = tnL <= tfL, hitR = tnR <= tfR;
-        int next = -1;  // inner node to descend into
-        int defer = -1; // inner node to push
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const bool h = side == 0 ? hitL : hitR;
-            const int child = side == 0 ? ch.x : ch.y;
-            if (h && child < 0) {  // leaf: one triangle
-                const int ti = ~child;
-                const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
-                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                RTX_COUNT(CNT_TRI_TESTS);
-                float t = 0.0f;
-                bool past_u = false;
-                const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
-                                       STATS ? &past_u : nullptr);
-                if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
-                if (th && t <= best_t) {
-                    // of two hits at the same distance the reference keeps the one it tests first
-                    int key = ti;
-                    if (s.mesh_cells) {
-                        // the triangle exists for this ray only if the ray passes a cell holding one
-                        // of its vertices; the i,j,k cell walk reaches it in the order of the keys
-                        const int4 keys = s.mesh_cells[ti];
-                        key = 0x7fffffff;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
-                            if (k < 0 || k >= key) continue;
-                            const float *cb = s.grid_cells + 6 * (k >> 22);
-                            const float lo[3] = {cb[0], cb[1], cb[2]}, hi[3] = {cb[3], cb[4], cb[5]};
-                            float cell_near = 0.0f;
-                            if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
-                        }
+            const int ti = ~cur;
+            const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
+            const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            RTX_COUNT(CNT_TRI_TESTS);
+            if constexpr (STATS) lc.v[CNT_TRI_TRIPS] += firstActiveLane() ? 1u : 0u;
+            float t = 0.0f;
+            bool past_u = false;
+            const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
+                                   STATS ? &past_u : nullptr);
+            if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
+            if (th && t <= best_t) {
+                // of two hits at the same distance the reference keeps the one it tests first
+                int key = ti;
+                if (s.mesh_cells) {
+                    // the triangle exists for this ray only if the ray passes a cell holding one of
+                    // its vertices; the i,j,k cell walk reaches it in the order of the keys
+                    const int4 keys = s.mesh_cells[ti];
+                    key = 0x7fffffff;
+#pragma unroll 1
+                    for (int c = 0; c < 3; ++c) {
+                        const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
+                        if (k < 0 || k >= key) continue;
+                        const float *cb = s.grid_cells + 6 * (k >> 22);
+                        const float lo[3] = {cb[0], cb[1], cb[2]}, hi[3] = {cb[3], cb[4], cb[5]};
+                        float cell_near = 0.0f;
+                        if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
                     }
-                    const bool take = key != 0x7fffffff && (t < best_t || (best_tri >= 0 && key < best_key));
-                    if (take) best_key = key;
-                    if (take) {
-                        best_t = t;
-                        best_tri = ti;
-                        if (SHADOW && t < t_exit) return true;
-                    }
+                }
+                if (key != 0x7fffffff && (t < best_t || (best_tri >= 0 && key < best_key))) {
+                    best_key = key;
+                    best_t = t;
+                    best_tri = ti;
+                    if (t < t_exit) return true;
                 }
             }
         }
-        const bool innerL = hitL && ch.x >= 0, innerR = hitR && ch.y >= 0;
-        if (innerL && innerR) {
-            const bool leftFirst = tnL <= tnR;
-            next = leftFirst ? ch.x : ch.y;
-            defer = leftFirst ? ch.y : ch.x;
-        } else if (innerL) {
-            next = ch.x;
-        } else if (innerR) {
-            next = ch.y;
-        }
-        if (defer >= 0) {
-            stack[sp * stride] = defer;
-            ++sp;
-        }
-        if (next < 0) {
-            if (sp == 0) break;
-            --sp;
-            next = stack[sp * stride];
-        }
-        node = next;
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * stride];
     }
     return false;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Scene::sceneIntersect, src/Scene.cpp:29-58: categories in the reference's order, each accepting
-// only a strictly nearer hit.
-//   SHADOW = false: fills h (point, normal, material copy with water / island colour override).
-//   SHADOW = true : only the distance matters; returns as soon as any hit nearer than t_exit is
-//                   known (the caller chooses t_exit so that the reference's own test
-//                   `distance(shadowPt, shadowOrig) < distance(light, point)` is then certain).
-// Returns `minDist < far_clip`; minDist itself comes back in min_dist.
+// only a strictly nearer hit.  It comes in three parts so that a wave can run the middle one -- the
+// mesh walk, by far the longest and the one few rays need -- for many lanes at once:
+//   castBegin: spheres, loose triangles, boxes, the mesh gate; says whether the walk is needed
+//   castMesh : the walk
+//   castEnd  : water plane, islands, then hit point / normal / material of the winner
+// Shadow rays (shadow = true) only need the distance; their categories are skipped as soon as any
+// hit nearer than t_exit is known (the caller chooses t_exit so that the reference's own test
+// `distance(shadowPt, shadowOrig) < distance(light, point)` is then certain).  Closest-hit rays
+// pass shadow = false and a negative t_exit.  `shadow` is a per-lane value: the lanes of a wave
+// cast both kinds side by side.
 // ---------------------------------------------------------------------------------------------
-template <bool SHADOW, bool STATS>
-RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, Hit &h, float &min_dist, float t_exit, int *stack,
-                            int stride, LaneCounters<STATS> &lc) {
+struct CastState {
+    float minDist;
+    int kind;   // what was hit last: 0 none, 1 sphere, 2 loose triangle, 3 box, 4 mesh triangle, 5 water, 6 island
+    int index;
+};
+
+template <bool STATS>
+RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, float t_exit, CastState &cs, LaneCounters<STATS> &lc) {
     float minDist = kFltMax;
-    // what was hit last: 0 none, 1 sphere, 2 loose triangle, 3 box, 4 mesh triangle, 5 water, 6 island
     int kind = 0, index = -1;
     const V3 inv = safeInverse(dir);
 
@@ -163,13 +181,9 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
                 kind = 1, index = i;
             }
         }
-        if (SHADOW && minDist < t_exit) {
-            min_dist = minDist;
-            return true;
-        }
     }
     // trianglesIntersect, :304-317
-    if (s.n_tris > 0 && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
+    if (s.n_tris > 0 && !(minDist < t_exit) && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
         for (int i = 0; i < s.n_tris; ++i) {
             const float *t = q.tris + 9 * i;
@@ -182,7 +196,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
         }
     }
     // cubesIntersect, :382-397
-    if (s.n_boxes > 0 && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
+    if (s.n_boxes > 0 && !(minDist < t_exit) && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
         for (int i = 0; i < s.n_boxes; ++i) {
             const float *b = q.boxes + 6 * i;
             const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
@@ -194,26 +208,28 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
                 kind = 3, index = i;
             }
         }
-        if (SHADOW && minDist < t_exit) {
-            min_dist = minDist;
-            return true;
-        }
     }
+    cs.minDist = minDist, cs.kind = kind, cs.index = index;
     // modelsIntersect, :350-380
-    if (s.n_mesh_tris > 0) {
-        int tri = -1;
-        float t = minDist;
-        if (meshIntersect<SHADOW, STATS>(s, orig, dir, inv, t, tri, t_exit, stack, stride, lc)) {
-            min_dist = t;
-            return true;
-        }
-        if (tri >= 0) {
-            minDist = t;
-            kind = 4, index = tri;
-        }
-    }
+    return s.n_mesh_tris > 0 && !(minDist < t_exit) && meshGate<STATS>(s, orig, dir, inv, lc);
+}
+
+template <bool STATS>
+RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastState &cs, int *stack, int stride, LaneCounters<STATS> &lc) {
+    int tri = -1;
+    float t = cs.minDist;
+    meshIntersect<STATS>(s, orig, dir, safeInverse(dir), t, tri, t_exit, stack, stride, lc);
+    if (tri >= 0) cs.minDist = t, cs.kind = 4, cs.index = tri;
+}
+
+// Returns `minDist < far_clip`; minDist itself comes back in min_dist.
+template <bool STATS>
+RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, const CastState &cs,
+                     Hit &h, float &min_dist, LaneCounters<STATS> &lc) {
+    float minDist = cs.minDist;
+    int kind = cs.kind, index = cs.index;
     // water plane, src/Scene.cpp:38-54
-    if (s.water_w > 0) {
+    if (s.water_w > 0 && !(minDist < t_exit)) {
         RTX_COUNT(CNT_PLANE_TESTS);
         float waterDist = kFltMax;
         if (planeHit(s.water_y, orig, dir, waterDist) && waterDist < minDist) {
@@ -224,7 +240,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
     // islandsIntersect, src/SceneObjects.cpp:399-419 with Island::rayIntersect :273-287.  Every
     // island that passes overrides the previous one (the loop compares with minDist, which it
     // does not update); minDist takes the last one's distance afterwards.
-    {
+    if (!(minDist < t_exit)) {
         float islandsDist = kFltMax;
         float dist = 0.0f;
         RTX_COUNT_N(CNT_PLANE_TESTS, s.n_islands > 0 ? 1 : 0);
@@ -247,7 +263,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
         minDist = fminf(islandsDist, minDist);
     }
     min_dist = minDist;
-    if (SHADOW) return minDist < s.far_clip;
+    if (shadow) return minDist < s.far_clip;
 
     // ---- resolve the winner: hit point, normal, material ----
     if (kind == 0) return false;
@@ -311,6 +327,14 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
     return minDist < s.far_clip;
 }
 
+template <bool STATS>
+RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, Hit &h,
+                            float &min_dist, int *stack, int stride, LaneCounters<STATS> &lc) {
+    CastState cs;
+    if (castBegin<STATS>(s, q, orig, dir, t_exit, cs, lc)) castMesh<STATS>(s, orig, dir, t_exit, cs, stack, stride, lc);
+    return castEnd<STATS>(s, q, orig, dir, shadow, t_exit, cs, h, min_dist, lc);
+}
+
 // Sky::getColorAt, src/SceneObjects.cpp:440-445.  atan2 and acos bind to the float overloads in
 // that translation unit; the two quotients are then formed in double and truncated to int; the
 // row shift wraps in uint32 before the modulo.  Texel = byte * (1/255.0f) (:429-434).
@@ -329,46 +353,15 @@ RTX_DEV V3 skyColor(const DevScene &s, V3 dir) {
     return v3((float)p[0] * k, (float)p[1] * k, (float)p[2] * k);
 }
 
-// Scene::calcLightning, src/Scene.cpp:60-81
-template <bool STATS>
-RTX_DEV void calcLighting(const DevScene &s, const SmallScene &q, V3 dir, V3 point, V3 N, float specular_exp, float &Ld, float &Ls,
-                          int *stack, int stride, LaneCounters<STATS> &lc) {
-    Ld = 0.0f, Ls = 0.0f;
-    const V3 positiveOrig = point + N * s.fprec, negativeOrig = point - N * s.fprec;
-    for (int i = 0; i < s.n_lights; ++i) {
-        const float4 L = q.lights[i];
-        const V3 lpos = v3(L.x, L.y, L.z);
-        const V3 lightDir = normalize(lpos - point);
-        const float ndl = dot(lightDir, N);
-        const V3 shadowOrig = __builtin_signbit(ndl) ? negativeOrig : positiveOrig;
-        const float lightDist = distance(lpos, point);
-        // A hit nearer than this decides the reference's test for certain: the closest hit is
-        // then at least that near, and |orig + dir*t - orig| differs from t by a few ulp only.
-        const float t_exit = fminf(lightDist * 0.999f, s.far_clip);
-        Hit dummy;
-        float minDist;
-        RTX_COUNT(CNT_SHADOW);
-        bool occluded = false;
-        if (sceneIntersect<true, STATS>(s, q, shadowOrig, lightDir, dummy, minDist, t_exit, stack, stride, lc)) {
-            if (minDist < t_exit) {
-                occluded = true;
-            } else {
-                const V3 shadowPt = shadowOrig + lightDir * minDist;
-                occluded = distance(shadowPt, shadowOrig) < lightDist;
-            }
-        }
-        if (occluded) continue;
-        RTX_COUNT(CNT_LIT);
-        if (ndl >= 0) Ld += L.w * ndl;
-        const float specIntDot = dot(-reflect(-lightDir, N), dir);
-        if (specIntDot >= 0) Ls += refPowf(q.math, specIntDot, specular_exp) * L.w;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Scene::traceRay, src/Scene.cpp:83-106, without recursion.  A frame is pushed for every hit
-// that has at least one child to wait for; children are traced reflect first, refract second, and
-// the sum is formed left to right exactly as at :103-105:
+// Scene::traceRay + Scene::calcLightning, src/Scene.cpp:60-106, as a state machine that advances
+// by ONE RAY per step: either the closest-hit ray of the next node of the call tree, or one shadow
+// ray of the node being shaded.  A wave interleaves the paths of 64 pixels at that granularity, so
+// a lane whose ray left the scene goes on to its next ray at once instead of idling while its
+// neighbours cast their shadow rays.
+//
+// A frame is pushed for every hit that has at least one child to wait for; children are traced
+// reflect first, refract second, and the sum is formed left to right exactly as at :103-105:
 //     ((diffuse*Ld*a0 + 1*Ls*a1) + reflect*a2) + refract*a3.
 // With pruning on, a child whose weight is exactly 0 is not traced and its (exactly zero)
 // contribution not added; x + 0*c == x for every finite c, so the result is unchanged.
@@ -380,78 +373,132 @@ struct Frame {
     int state;       // bit0: waiting for reflect, bit1: refract still to do, bit2: waiting for refract, bits 8..: depth of this node
 };
 
-// One path = one traceRay call tree, walked one node per step so that a wave can interleave the
-// paths of different pixels (lanes that finish take a new pixel while their neighbours go deeper).
 struct PathState {
-    V3 orig, dir;
-    int depth;      // remaining depth of the node to evaluate next
+    V3 orig, dir;   // the ray to cast next
+    float t_exit;   // shadow ray: early-exit distance
+    int light;      // < 0: the ray is a closest-hit ray; >= 0: shadow ray towards this light
+    int depth;      // remaining depth of the node the ray belongs to
     int fullDepth;  // depth of the root (statistics only)
     int sp;         // frames in use
-    Frame frames[kMaxDepth];
+    // the node being shaded (valid while light >= 0)
+    V3 point, N, view;
+    Material m;
+    float ndl, lightDist, Ld, Ls;
 };
 
 RTX_DEV void pathStart(PathState &st, V3 orig, V3 dir, int depth) {
     st.orig = orig, st.dir = dir, st.depth = depth, st.fullDepth = depth, st.sp = 0;
+    st.light = -1, st.t_exit = -1.0f;
 }
 
-// Evaluates the next node of the path.  Returns true when the whole tree is done; `color` is then
-// the value traceRay would have returned.
+// Does the pending ray have to be cast at all?  (A closest-hit ray of depth 0 is answered by the sky.)
+RTX_DEV bool pathCasts(const PathState &st) { return st.light >= 0 || st.depth > 0; }
+
 template <bool STATS>
-RTX_DEV bool pathStep(const DevScene &s, const SmallScene &q, PathState &st, V3 &color, int *stack, int stride, LaneCounters<STATS> &lc) {
-    const V3 orig = st.orig, dir = st.dir;
-    const int depth = st.depth;
-    bool hit = false;
-    Hit h;
-    if (depth > 0) {
-        if constexpr (STATS) lc.v[depth == st.fullDepth ? CNT_PRIMARY : CNT_SECONDARY]++;
-        float md;
-        hit = sceneIntersect<false, STATS>(s, q, orig, dir, h, md, 0.0f, stack, stride, lc);
+RTX_DEV void pathCountRay(const PathState &st, LaneCounters<STATS> &lc) {
+    if constexpr (STATS) {
+        const bool shadow = st.light >= 0;
+        lc.v[CNT_SHADOW] += shadow ? 1u : 0u;
+        lc.v[CNT_PRIMARY] += !shadow && st.depth == st.fullDepth ? 1u : 0u;
+        lc.v[CNT_SECONDARY] += !shadow && st.depth != st.fullDepth ? 1u : 0u;
     }
-    if (!hit) {
+}
+
+// Consumes the result of the pending ray (hit, h, md: what castEnd returned; hit = false when the ray
+// was not cast) and sets up the next one.  Returns true when the whole tree is done; `color` is
+// then the value traceRay would have returned.
+template <bool STATS>
+RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool hit, const Hit &h, float md,
+                         V3 &color, LaneCounters<STATS> &lc) {
+    const bool shadow = st.light >= 0;
+    bool returning = false;  // `color` holds the finished value of a node
+    if (shadow) {
+        // ---- one light of calcLightning, :64-79, after its shadow ray ----
+        bool occluded = false;
+        if (hit) {
+            if (md < st.t_exit) {
+                occluded = true;
+            } else {
+                const V3 shadowPt = st.orig + st.dir * md;
+                occluded = distance(shadowPt, st.orig) < st.lightDist;
+            }
+        }
+        if (!occluded) {
+            RTX_COUNT(CNT_LIT);
+            const float intensity = q.lights[st.light].w;
+            if (st.ndl >= 0) st.Ld += intensity * st.ndl;
+            const float specIntDot = dot(-reflect(-st.dir, st.N), st.view);
+            if (specIntDot >= 0) st.Ls += refPowf(q.math, specIntDot, st.m.spec) * intensity;
+        }
+        ++st.light;
+    } else if (!hit) {
         RTX_COUNT(CNT_SKY);
-        color = skyColor(s, dir);
+        color = skyColor(s, st.dir);
+        returning = true;
     } else {
-        float Ld, Ls;
-        calcLighting<STATS>(s, q, dir, h.point, h.N, h.m.spec, Ld, Ls, stack, stride, lc);
-        const V3 base = v3(h.m.dr * Ld * h.m.a0, h.m.dg * Ld * h.m.a0, h.m.db * Ld * h.m.a0) +
-                        v3(Ls * h.m.a1, Ls * h.m.a1, Ls * h.m.a1);
-        const bool doRefl = !s.prune || h.m.a2 != 0.0f;
-        const bool doRefr = !s.prune || h.m.a3 != 0.0f;
+        st.point = h.point, st.N = h.N, st.m = h.m, st.view = st.dir;
+        st.Ld = 0.0f, st.Ls = 0.0f;
+        st.light = 0;
+    }
+    if (!returning) {
+        if (st.light < s.n_lights) {
+            // ---- the next shadow ray, :65-70 ----
+            const float4 L = q.lights[st.light];
+            const V3 lpos = v3(L.x, L.y, L.z);
+            const V3 lightDir = normalize(lpos - st.point);
+            st.ndl = dot(lightDir, st.N);
+            const V3 off = st.N * s.fprec;
+            st.orig = __builtin_signbit(st.ndl) ? st.point - off : st.point + off;
+            st.dir = lightDir;
+            st.lightDist = distance(lpos, st.point);
+            // A hit nearer than this decides the reference's test for certain: the closest hit is
+            // then at least that near, and |orig + dir*t - orig| differs from t by a few ulp only.
+            st.t_exit = fminf(st.lightDist * 0.999f, s.far_clip);
+            return false;
+        }
+        // ---- all lights done: the node's own colour and its children, :96-105 ----
+        st.light = -1, st.t_exit = -1.0f;
+        const Material &m = st.m;
+        const V3 dir = st.view;
+        const int depth = st.depth;
+        const V3 base = v3(m.dr * st.Ld * m.a0, m.dg * st.Ld * m.a0, m.db * st.Ld * m.a0) + v3(st.Ls * m.a1, st.Ls * m.a1, st.Ls * m.a1);
+        const bool doRefl = !s.prune || m.a2 != 0.0f;
+        const bool doRefr = !s.prune || m.a3 != 0.0f;
         if (!doRefl && !doRefr) {
             color = base;
         } else {
-            const V3 positiveOrig = h.point + h.N * s.fprec, negativeOrig = h.point - h.N * s.fprec;
+            const V3 positiveOrig = st.point + st.N * s.fprec, negativeOrig = st.point - st.N * s.fprec;
             V3 reflD = v3(0, 0, 0), refrD = v3(0, 0, 0);
-            if (doRefl) reflD = normalize(reflect(dir, h.N));
-            if (doRefr) refrD = normalize(refractDir(dir, h.N, h.m.refractive));
+            if (doRefl) reflD = normalize(reflect(dir, st.N));
+            if (doRefr) refrD = normalize(refractDir(dir, st.N, m.refractive));
             if (depth == 1) {
                 // the children have depth 0: traceRay returns the sky colour of their direction at
                 // once (src/Scene.cpp:87-88), so they are evaluated in place
                 V3 c = base;
                 if (doRefl) {
                     RTX_COUNT(CNT_SKY);
-                    c = c + skyColor(s, reflD) * h.m.a2;
+                    c = c + skyColor(s, reflD) * m.a2;
                 }
                 if (doRefr) {
                     RTX_COUNT(CNT_SKY);
-                    c = c + skyColor(s, refrD) * h.m.a3;
+                    c = c + skyColor(s, refrD) * m.a3;
                 }
                 color = c;
             } else {
                 Frame f;
                 f.acc = base;
-                f.a2 = h.m.a2, f.a3 = h.m.a3;
+                f.a2 = m.a2, f.a3 = m.a3;
                 f.state = (doRefl ? 1 : 0) | (doRefr ? 2 : 0) | (depth << 8);
                 f.rdir = refrD;
-                f.rorig = __builtin_signbit(dot(refrD, h.N)) ? negativeOrig : positiveOrig;
+                f.rorig = __builtin_signbit(dot(refrD, st.N)) ? negativeOrig : positiveOrig;
                 if (doRefl) {
-                    st.orig = __builtin_signbit(dot(reflD, h.N)) ? negativeOrig : positiveOrig;
+                    st.orig = __builtin_signbit(dot(reflD, st.N)) ? negativeOrig : positiveOrig;
                     st.dir = reflD;
                 } else {
                     st.orig = f.rorig, st.dir = f.rdir;
                     f.state = (f.state & ~2) | 4;
                 }
-                st.frames[st.sp++] = f;
+                frames[st.sp++] = f;
                 st.depth = depth - 1;
                 return false;
             }
@@ -459,7 +506,7 @@ RTX_DEV bool pathStep(const DevScene &s, const SmallScene &q, PathState &st, V3 
     }
     // ---- return `color` to the waiting frames ----
     while (st.sp > 0) {
-        Frame &f = st.frames[st.sp - 1];
+        Frame &f = frames[st.sp - 1];
         if (f.state & 1) {  // reflect child returned
             f.acc = f.acc + color * f.a2;
             f.state &= ~1;
@@ -482,11 +529,19 @@ RTX_DEV bool pathStep(const DevScene &s, const SmallScene &q, PathState &st, V3 
 template <bool STATS>
 RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
     PathState st;
+    Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
     pathStart(st, orig, dir, depth);
     V3 color = v3(0, 0, 0);
-    while (!pathStep<STATS>(s, q, st, color, stack, stride, lc)) {
+    for (;;) {
+        bool hit = false;
+        Hit h;
+        float md = 0.0f;
+        if (pathCasts(st)) {
+            pathCountRay<STATS>(st, lc);
+            hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
+        }
+        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, color, lc)) return color;
     }
-    return color;
 }
 
 }  // namespace rtx

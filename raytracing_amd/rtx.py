@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(_PKG, "librtx_hip.so")
 ASSETS_DIR = os.path.join(os.path.dirname(_PKG), "assets")
 
 MASK_SPHERES, MASK_CUBES, MASK_TRIANGLES, MASK_MODEL, MASK_ISLANDS, MASK_ALL = 1, 2, 4, 8, 16, 31
-OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID = 1, 2, 3, 4, 5
+OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID, OPT_BVH_BUILDER = 1, 2, 3, 4, 5, 6
 
 
 class RtxError(RuntimeError):
@@ -37,7 +37,7 @@ class Stats(C.Structure):
                 ("sky_lookups", C.c_uint64), ("mesh_box_hits", C.c_uint64), ("bvh_node_tests", C.c_uint64),
                 ("triangle_tests", C.c_uint64), ("triangle_full", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("loose_tri_tests", C.c_uint64), ("box_tests", C.c_uint64), ("plane_tests", C.c_uint64),
-                ("island_tests", C.c_uint64), ("lit_lights", C.c_uint64), ("reserved", C.c_uint64 * 2),
+                ("island_tests", C.c_uint64), ("lit_lights", C.c_uint64), ("node_wave_trips", C.c_uint64), ("tri_wave_trips", C.c_uint64),
                 ("kernel_ms", C.c_double)]
 
     @property
@@ -46,7 +46,7 @@ class Stats(C.Structure):
         return self.primary_rays + self.secondary_rays + self.shadow_rays
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 # every symbol include/rtx.h and include/rt_host.h declare; the test suite checks the libraries export them all

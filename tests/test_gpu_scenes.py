@@ -6,7 +6,7 @@ import pytest
 
 from conftest import PSNR_MIN_DB, WITHIN_ONE_MIN, compare_frames, make_default_context
 from raytracing_amd.distributed import assemble_rows, owned_rows, rows_per_rank
-from raytracing_amd.rtx import OPT_MESH_GRID, RtxError
+from raytracing_amd.rtx import OPT_BVH_BUILDER, OPT_MESH_GRID, RtxError
 
 pytestmark = pytest.mark.gpu
 
@@ -77,8 +77,30 @@ def test_mesh_with_grid_cells_equals_oracle_mesh(hip, oracle_backend, textures, 
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures):
-    """All triangles share one centroid (identical Morton codes): the tree must still be valid."""
+@pytest.mark.parametrize("n_tris", [1, 2, 5, 300, 20000])
+def test_both_tree_builders_give_the_same_hits(hip, textures, n_tris):
+    """Morton-order build on the GPU vs surface-area-heuristic build on the host: the tree only steers
+    the walk, so every hit record must be identical (ties between equal distances included)."""
+    verts, idx = _soup(n_tris, 900 + n_tris)
+    o, d = _rays(20000, 11 + n_tris)
+    out = []
+    for builder in (1, 2):
+        c = hip.create()
+        c.set_materials(hip.default_materials())
+        c.set_mesh(verts, idx, 3)
+        c.set_envmap(textures["map.jpg"])
+        c.set_option(OPT_BVH_BUILDER, builder)
+        c.set_option(OPT_MESH_GRID, 0)
+        c.commit()
+        out.append(c.intersect_rays(o, d))
+    assert (out[0][:, 0] > 0).sum() > (0 if n_tris < 300 else 100)
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("builder", [1, 2])
+def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures, builder):
+    """All triangles share one centroid (identical Morton codes, no usable split plane): the tree
+    must still be valid."""
     base = np.array([[-1, -1, -20], [1, -1, -20], [0, 1, -20]], np.float32)
     verts = np.concatenate([base + np.array([0, 0, -0.01 * k], np.float32) for k in range(40)])
     idx = np.arange(120, dtype=np.int32).reshape(40, 3)
@@ -87,6 +109,7 @@ def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures):
     g.set_mesh(verts, idx, 3)
     g.set_envmap(textures["map.jpg"])
     g.set_option(OPT_MESH_GRID, 0)
+    g.set_option(OPT_BVH_BUILDER, builder)
     g.commit()
     o = np.array([[0, 0, 0], [0.2, -0.3, 0], [5, 5, 0]], np.float32)
     d = np.array([[0, 0, -1], [0, 0, -1], [0, 0, -1]], np.float32)
