@@ -90,9 +90,10 @@ struct DevScene {
     // The reference bins every mesh triangle into the cells of a 7x7x7 grid that hold its vertices
     // and tests it only for rays that pass one of those cells (src/SceneObjects.cpp:176-209,
     // 350-380).  mesh_cells[t] = up to three keys (cell index << 22 | position in the cell's list,
-    // -1 = unused); grid_cells = lo xyz, hi xyz per cell.  Null when that filter is switched off.
+    // -1 = unused), null when that filter is switched off; cell (i, j, k), index (i*7 + j)*7 + k,
+    // spans mesh_lo + grid_step * (i, j, k) .. mesh_lo + grid_step * (i+1, j+1, k+1).
     const int4 *mesh_cells;
-    const float *grid_cells;
+    float grid_step[3];
     // conservative bounds of whole categories (lo xyz, hi xyz), padded: a ray that misses one
     // cannot hit anything inside, so the exact per-primitive tests are skipped for it
     float sphere_bounds[6], tri_bounds[6], box_bounds[6];

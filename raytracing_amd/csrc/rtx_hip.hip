@@ -81,7 +81,7 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
 constexpr unsigned kQueues = 64, kHeadStride = 32;
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, unsigned *heads,
                                                    unsigned char *__restrict__ out, Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
@@ -295,24 +295,16 @@ int bind(rtx_ctx *c) {
 }
 
 // BoundingBox::init + initTriangles, src/SceneObjects.cpp:176-209: the 7x7x7 cells of the padded
-// vertex bounds and, per triangle, the cells its vertices fall into.  cells = lo xyz, hi xyz per
-// cell in i,j,k order; keys = four ints per triangle: (cell << 22 | position in that cell's list)
-// for each distinct cell, -1 for unused slots.  Arithmetic as the reference writes it (binary32,
-// no contraction), so that a vertex on a cell boundary lands in the same cell.
+// vertex bounds and, per triangle, the cells its vertices fall into.  step = edge lengths of a cell
+// (the device forms the cell boxes from it the way the reference does: lo + step * i); keys = four
+// ints per triangle: (cell << 22 | position in that cell's list) for each distinct cell, cell =
+// (i*7 + j)*7 + k, -1 for unused slots.  Arithmetic as the reference writes it (binary32, no
+// contraction), so that a vertex on a cell boundary lands in the same cell.
 void gridCells(const std::vector<float> &verts, const std::vector<int> &idx, const float lo[3], const float hi[3],
-               std::vector<float> &cells, std::vector<int> &keys) {
+               float step[3], std::vector<int> &keys) {
     const int size = 7;
     const float lx = hi[0] - lo[0], ly = hi[1] - lo[1], lz = hi[2] - lo[2];
-    const float px = lx / float(size), py = ly / float(size), pz = lz / float(size);
-    cells.resize((size_t)size * size * size * 6);
-    for (int i = 0; i < size; ++i)
-        for (int j = 0; j < size; ++j)
-            for (int k = 0; k < size; ++k) {
-                const float a[3] = {lo[0] + px * i, lo[1] + py * j, lo[2] + pz * k};
-                const float b[3] = {lo[0] + px * (i + 1), lo[1] + py * (j + 1), lo[2] + pz * (k + 1)};
-                float *c = &cells[(size_t)((i * size + j) * size + k) * 6];
-                for (int t = 0; t < 3; ++t) c[t] = a[t] < b[t] ? a[t] : b[t], c[3 + t] = a[t] < b[t] ? b[t] : a[t];  // Cube::load
-            }
+    step[0] = lx / float(size), step[1] = ly / float(size), step[2] = lz / float(size);
     const size_t nt = idx.size() / 3;
     keys.assign(nt * 4, -1);
     std::vector<int> fill((size_t)size * size * size, 0);
@@ -761,16 +753,13 @@ int rtx_commit(rtx_ctx *c) {
         }
         c->bvh_depth = r.max_depth;
         d.mesh_tris = r.tris, d.bvh = r.nodes, d.n_mesh_tris = nt, d.mesh_mat = c->mesh_mat;
-        d.mesh_cells = nullptr, d.grid_cells = nullptr;
+        d.mesh_cells = nullptr;
         if (c->mesh_grid) {
-            std::vector<float> cells;
             std::vector<int> keys;
-            gridCells(c->mesh_verts, c->mesh_idx, d.mesh_lo, d.mesh_hi, cells, keys);
-            float *dc;
+            gridCells(c->mesh_verts, c->mesh_idx, d.mesh_lo, d.mesh_hi, d.grid_step, keys);
             int *dk;
-            if (int e = upload(cells, &dc, c->owned)) return e;
             if (int e = upload(keys, &dk, c->owned)) return e;
-            d.grid_cells = dc, d.mesh_cells = reinterpret_cast<const int4 *>(dk);
+            d.mesh_cells = reinterpret_cast<const int4 *>(dk);
         }
     }
     c->committed = true;

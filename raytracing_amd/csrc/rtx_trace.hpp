@@ -105,6 +105,9 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
             const int ti = ~cur;
             const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
             const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+            // fetched with the triangle, not after the test: a dependent load would double the latency
+            int4 keys = make_int4(-1, -1, -1, -1);
+            if (s.mesh_cells) keys = s.mesh_cells[ti];
             RTX_COUNT(CNT_TRI_TESTS);
             if constexpr (STATS) lc.v[CNT_TRI_TRIPS] += firstActiveLane() ? 1u : 0u;
             float t = 0.0f;
@@ -118,14 +121,18 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                 if (s.mesh_cells) {
                     // the triangle exists for this ray only if the ray passes a cell holding one of
                     // its vertices; the i,j,k cell walk reaches it in the order of the keys
-                    const int4 keys = s.mesh_cells[ti];
                     key = 0x7fffffff;
 #pragma unroll 1
                     for (int c = 0; c < 3; ++c) {
                         const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
                         if (k < 0 || k >= key) continue;
-                        const float *cb = s.grid_cells + 6 * (k >> 22);
-                        const float lo[3] = {cb[0], cb[1], cb[2]}, hi[3] = {cb[3], cb[4], cb[5]};
+                        // the cell's box as BoundingBox::init computes it, src/SceneObjects.cpp:183-192
+                        const int cell = k >> 22;
+                        const int ci = cell / 49, cj = (cell / 7) % 7, ck = cell % 7;
+                        const float lo[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)ci, s.mesh_lo[1] + s.grid_step[1] * (float)cj,
+                                             s.mesh_lo[2] + s.grid_step[2] * (float)ck};
+                        const float hi[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)(ci + 1), s.mesh_lo[1] + s.grid_step[1] * (float)(cj + 1),
+                                             s.mesh_lo[2] + s.grid_step[2] * (float)(ck + 1)};
                         float cell_near = 0.0f;
                         if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
                     }

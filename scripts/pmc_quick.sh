@@ -1,16 +1,19 @@
 #!/bin/bash
-# Quick counter passes over the render kernel (bench.py, few steps).  usage: bash scripts/pmc_quick.sh <tag>
+# Quick counter passes over the render kernel (bench.py, few steps).  usage: bash scripts/pmc_quick.sh <tag> ["counters of one pass" ...]
 set -u
 TAG=${1:-q}
+shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+if [ $# -eq 0 ]; then
+  set -- "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
+         "SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_SCA" \
+         "GRBM_GUI_ACTIVE"
+fi
 i=0
-for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
-            "SQ_WAIT_INST_ANY SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_SCA" \
-            "GRBM_GUI_ACTIVE GRBM_COUNT" \
-            "SQ_INST_CYCLES_SALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32"; do
+for pass in "$@"; do
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $pass -d "$OUT/p$i" -o "$TAG" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/p$i.log"; }
 done
@@ -23,5 +26,5 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]
-    print("%-26s %16.0f  (n=%d)" % (k, sum(v) / len(v), len(v)))
+    print("%-32s %16.0f  (n=%d)" % (k, sum(v) / len(v), len(v)))
 PY
