@@ -86,18 +86,19 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                 tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
             }
             const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
-            if (hitL && hitR) {
-                const bool leftFirst = tnL <= tnR;
-                stack[sp * stride] = leftFirst ? ch.y : ch.x;
-                ++sp;
-                cur = leftFirst ? ch.x : ch.y;
-            } else if (hitL || hitR) {
-                cur = hitL ? ch.x : ch.y;
-            } else if (sp > 0) {
-                --sp;
-                cur = stack[sp * stride];
-            } else {
+            // near child (or the only one hit) next, the far one onto the stack; written without
+            // nested branches: the store is harmless when nothing is pushed (the slot is free)
+            const bool both = hitL && hitR;
+            const bool leftNext = hitL && (!hitR || tnL <= tnR);
+            stack[sp * stride] = leftNext ? ch.y : ch.x;
+            sp += both ? 1 : 0;
+            cur = leftNext ? ch.x : ch.y;
+            if (!(hitL || hitR)) {
                 cur = kDone;
+                if (sp > 0) {
+                    --sp;
+                    cur = stack[sp * stride];
+                }
             }
         }
         if (cur == kDone) break;
