@@ -86,10 +86,13 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_render(DevScene s, De
                                                    unsigned char *__restrict__ out, Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
+    __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
     loadSmallScene(q, s);
     __syncthreads();
     int *stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
+    // rows of whole dwords: a finished tile goes out as 48 dword stores instead of 192 byte stores
+    const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
     const unsigned my_len = lane < n_tiles ? (n_tiles - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
     unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
@@ -120,12 +123,15 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_render(DevScene s, De
             qi = (unsigned)__builtin_ctzll(after ? after : live);
         }
         if (tile == 0xffffffffu) break;  // every queue is empty
-        const int px = (int)(tile % tiles_x) * 8 + (int)(lane & 7u);
-        const int pk = (int)(tile / tiles_x) * 8 + (int)(lane >> 3);
-        bool active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
-        if (active) {
-            const int row = fr.row_first + pk * fr.row_step;
-            pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
+        const int x0 = (int)(tile % tiles_x) * 8, y0 = (int)(tile / tiles_x) * 8;
+        bool active;
+        {
+            const int px = x0 + (int)(lane & 7u), pk = y0 + (int)(lane >> 3);
+            active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
+            if (active) {
+                const int row = fr.row_first + pk * fr.row_step;
+                pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
+            }
         }
         // ---- trace its 64 paths ----
         while (active) {
@@ -138,11 +144,33 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_render(DevScene s, De
             }
             V3 c;
             if (pathConsume<STATS>(s, q, st, frames, hit, h, md, c, lc)) {
-                unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
+                unsigned char *p = &s_tile[threadIdx.x >> 6][3 * lane];
                 p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
                 active = false;
             }
         }
+        // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
+        // fences keep the compiler from moving the reads above the byte writes. ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (dword_rows && x0 + 8 <= fr.width && y0 + 8 <= fr.rows) {
+            // 8 rows of 24 bytes = 48 dword stores instead of 192 byte stores
+            if (lane < 48u) {
+                const unsigned r = lane / 6u, w = lane % 6u;
+                unsigned *dst = reinterpret_cast<unsigned *>(out + ((size_t)(y0 + (int)r) * fr.width + x0) * 3) + w;
+                *dst = *reinterpret_cast<const unsigned *>(&s_tile[threadIdx.x >> 6][4 * lane]);
+            }
+        } else {
+            const int px = x0 + (int)(lane & 7u), pk = y0 + (int)(lane >> 3);
+            if (px < fr.width && pk < fr.rows) {
+                const unsigned char *src = &s_tile[threadIdx.x >> 6][3 * lane];
+                unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
+                p[0] = src[0], p[1] = src[1], p[2] = src[2];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     flushCounters<STATS>(lc, counters);
 }

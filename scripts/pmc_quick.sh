@@ -18,13 +18,14 @@ for pass in "$@"; do
   timeout -s KILL 120 rocprofv3 --pmc $pass -d "$OUT/p$i" -o "$TAG" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/p$i.log"; }
 done
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-acc = collections.defaultdict(list)
+import csv, glob, sys, statistics
+acc = {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_render<false" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 for k in sorted(acc):
-    v = acc[k]
-    print("%-32s %16.0f  (n=%d)" % (k, sum(v) / len(v), len(v)))
+    v = sorted(acc[k].values())
+    print("%-32s %16.0f  (median of %d launches)" % (k, statistics.median(v), len(v)))
 PY
