@@ -81,7 +81,7 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
 constexpr unsigned kQueues = 64, kHeadStride = 32;
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, unsigned *heads,
                                                    unsigned char *__restrict__ out, Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];

@@ -1,3 +1,4 @@
+"""Kernel time and ray / node statistics of the HIP path per scene subset and depth at 3840x2160 (run on a GPU box)."""
 import sys, os
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))

@@ -1,3 +1,4 @@
+"""Kernel time of the HIP path against frame size, per scene subset (run on a GPU box)."""
 import sys, os
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
