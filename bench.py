@@ -48,6 +48,7 @@ FLOPS = {
 }
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA); = the f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMD16; 157.3 TFLOP/s = 1024 x 16 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
 
 
 def algorithmic_flops(st, n_pixels):
@@ -197,13 +198,24 @@ def main():
         kernel_ms = ms.value / n_launch
         flops = algorithmic_flops(st, rows * WIDTH)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        # counters of the same kernel on the same frame, from the committed rocprofv3 passes
+        traffic, issue = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_render_hbm_bytes_per_launch_n%d" % world)
+                prof = json.load(open(tpath))
+                traffic = prof.get("k_render_hbm_bytes_per_launch_n%d" % world)
+                wave_insts = prof.get("k_render_valu_wave_insts_per_launch_n%d" % world)
+                lane_insts = prof.get("k_render_valu_lane_insts_per_launch_n%d" % world)
+                if wave_insts and lane_insts:
+                    # one wave64 VALU instruction occupies its SIMD for 4 clocks; 1024 SIMDs; 64 lanes/CU/clk
+                    issue = {"valu_wave_insts_per_launch": int(wave_insts), "valu_lane_insts_per_launch": int(lane_insts),
+                             "simd_issue_frac": round(wave_insts * 4 / (N_SIMD * CLOCK_HZ * kernel_ms * 1e-3), 4),
+                             "lane_slot_frac": round(lane_insts / (N_SIMD * 16 * CLOCK_HZ * kernel_ms * 1e-3), 4),
+                             "mean_active_lanes": round(lane_insts / wave_insts, 1),
+                             "source": "profiles/traffic.json (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU) / live kernel time"}
             except Exception:
-                traffic = None
+                traffic, issue = None, None
         # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
         roofline = {
@@ -212,6 +224,7 @@ def main():
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
                     "the reference bit for bit, so 1 flop/lane/clk = 39.3 TFLOP/s is the most such code can reach",
+            "valu_issue": issue,
             "hbm": {"algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gbs": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 1),
                     "peak_gbs": PEAK_HBM_GBS, "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
         }
