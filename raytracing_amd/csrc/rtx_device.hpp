@@ -94,6 +94,8 @@ struct DevScene {
     // spans mesh_lo + grid_step * (i, j, k) .. mesh_lo + grid_step * (i+1, j+1, k+1).
     const int4 *mesh_cells;
     float grid_step[3];
+    float grid_inv_step[3];  // approximate 1 / grid_step, for the hit-point shortcut only
+    float grid_fast_tmax;    // hits beyond this distance never take the shortcut (0 disables it)
     // conservative bounds of whole categories (lo xyz, hi xyz), padded: a ray that misses one
     // cannot hit anything inside, so the exact per-primitive tests are skipped for it
     float sphere_bounds[6], tri_bounds[6], box_bounds[6];

@@ -788,6 +788,15 @@ int rtx_commit(rtx_ctx *c) {
             int *dk;
             if (int e = upload(keys, &dk, c->owned)) return e;
             d.mesh_cells = reinterpret_cast<const int4 *>(dk);
+            // the hit-point shortcut of the mesh walk needs its 1e-3-of-a-cell margin to stay far above
+            // float rounding: cells not tiny against the coordinates, hits not too far away
+            float min_step = d.grid_step[0], max_abs = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                min_step = std::fmin(min_step, d.grid_step[k]);
+                max_abs = std::fmax(max_abs, std::fmax(std::fabs(d.mesh_lo[k]), std::fabs(d.mesh_hi[k])));
+                d.grid_inv_step[k] = d.grid_step[k] > 0.0f ? 1.0f / d.grid_step[k] : 0.0f;
+            }
+            d.grid_fast_tmax = (min_step > 0.0f && max_abs < 500.0f * min_step) ? 500.0f * min_step : 0.0f;
         }
     }
     c->committed = true;

@@ -47,6 +47,28 @@ RTX_DEV bool meshGate(const DevScene &s, V3 orig, V3 dir, V3 inv, LaneCounters<S
     return true;
 }
 
+constexpr int kNoCell = 0x7fffffff, kKeyOpen = 0x7ffffffe;
+
+// Smallest key among the triangle's cells whose box the ray passes under the reference's own slab
+// test; the cell boxes are formed as BoundingBox::init forms them, src/SceneObjects.cpp:183-192.
+RTX_DEV int cellKey(const DevScene &s, int4 keys, V3 orig, V3 dir, V3 inv) {
+    int key = kNoCell;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
+        if (k < 0 || k >= key) continue;
+        const int cell = k >> 22;
+        const int ci = cell / 49, cj = (cell / 7) % 7, ck = cell % 7;
+        const float lo[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)ci, s.mesh_lo[1] + s.grid_step[1] * (float)cj,
+                             s.mesh_lo[2] + s.grid_step[2] * (float)ck};
+        const float hi[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)(ci + 1), s.mesh_lo[1] + s.grid_step[1] * (float)(cj + 1),
+                             s.mesh_lo[2] + s.grid_step[2] * (float)(ck + 1)};
+        float cell_near = 0.0f;
+        if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
+    }
+    return key;
+}
+
 template <bool STATS>
 RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
                            int *stack, int stride, LaneCounters<STATS> &lc) {
@@ -62,7 +84,7 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
     constexpr int kDone = (int)0x80000000;
     int sp = 0;
     int cur = 0;
-    int best_key = 0x7fffffff;  // order in which the reference's walk reaches best_tri
+    int best_key = kNoCell;  // order in which the reference's walk reaches best_tri
     for (;;) {
         while (cur >= 0) {
             const float4 *np = reinterpret_cast<const float4 *>(s.bvh + cur);
@@ -117,28 +139,40 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                                    STATS ? &past_u : nullptr);
             if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
             if (th && t <= best_t) {
-                // of two hits at the same distance the reference keeps the one it tests first
+                // The reference tests a triangle only for rays that pass (Cube::rayIntersect) a grid
+                // cell holding one of its vertices, and of two hits at the same distance it keeps the
+                // one its i,j,k cell walk reaches first.  key = that order (cell, position in the
+                // cell's list); kNoCell = the ray passes none of the triangle's cells.
                 int key = ti;
                 if (s.mesh_cells) {
-                    // the triangle exists for this ray only if the ray passes a cell holding one of
-                    // its vertices; the i,j,k cell walk reaches it in the order of the keys
-                    key = 0x7fffffff;
-#pragma unroll 1
-                    for (int c = 0; c < 3; ++c) {
-                        const int k = c == 0 ? keys.x : (c == 1 ? keys.y : keys.z);
-                        if (k < 0 || k >= key) continue;
-                        // the cell's box as BoundingBox::init computes it, src/SceneObjects.cpp:183-192
-                        const int cell = k >> 22;
-                        const int ci = cell / 49, cj = (cell / 7) % 7, ck = cell % 7;
-                        const float lo[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)ci, s.mesh_lo[1] + s.grid_step[1] * (float)cj,
-                                             s.mesh_lo[2] + s.grid_step[2] * (float)ck};
-                        const float hi[3] = {s.mesh_lo[0] + s.grid_step[0] * (float)(ci + 1), s.mesh_lo[1] + s.grid_step[1] * (float)(cj + 1),
-                                             s.mesh_lo[2] + s.grid_step[2] * (float)(ck + 1)};
-                        float cell_near = 0.0f;
-                        if (slabMaybe(lo, hi, orig, inv) && boxSlab(lo, hi, orig, dir, cell_near)) key = k;
+                    key = kNoCell;
+                    // Shortcut for the common case: the hit point lies well inside one of the
+                    // triangle's cells, so the ray certainly passes that cell's box (the margin is
+                    // orders of magnitude above the rounding of the slab test; directions with a
+                    // component below the slab test's parallel threshold, far hits and exact ties
+                    // take the long way).  The order key is then left open (kKeyOpen) and only
+                    // worked out if a tie ever needs it.
+                    if (t < best_t && t < s.grid_fast_tmax && fabsf(dir.x) >= kEps && fabsf(dir.y) >= kEps && fabsf(dir.z) >= kEps) {
+                        const V3 p = orig + dir * t;
+                        const float rx = (p.x - s.mesh_lo[0]) * s.grid_inv_step[0], ry = (p.y - s.mesh_lo[1]) * s.grid_inv_step[1],
+                                    rz = (p.z - s.mesh_lo[2]) * s.grid_inv_step[2];
+                        const float fx = floorf(rx), fy = floorf(ry), fz = floorf(rz);
+                        const float lo_m = fminf(fminf(rx - fx, ry - fy), rz - fz), hi_m = fmaxf(fmaxf(rx - fx, ry - fy), rz - fz);
+                        if (lo_m >= 1e-3f && hi_m <= 0.999f && fminf(fminf(fx, fy), fz) >= 0.0f && fmaxf(fmaxf(fx, fy), fz) <= 6.0f) {
+                            const int cell = ((int)fx * 7 + (int)fy) * 7 + (int)fz;
+                            if ((keys.x >= 0 && (keys.x >> 22) == cell) || (keys.y >= 0 && (keys.y >> 22) == cell) ||
+                                (keys.z >= 0 && (keys.z >> 22) == cell))
+                                key = kKeyOpen;
+                        }
                     }
+                    if (key == kNoCell) key = cellKey(s, keys, orig, dir, inv);
                 }
-                if (key != 0x7fffffff && (t < best_t || (best_tri >= 0 && key < best_key))) {
+                bool take = key != kNoCell && t < best_t;
+                if (key != kNoCell && t == best_t && best_tri >= 0) {  // a tie: both keys exactly
+                    if (best_key == kKeyOpen) best_key = cellKey(s, s.mesh_cells[best_tri], orig, dir, inv);
+                    take = key < best_key;
+                }
+                if (take) {
                     best_key = key;
                     best_t = t;
                     best_tri = ti;
