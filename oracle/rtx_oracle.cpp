@@ -458,6 +458,14 @@ Lightning calcLightning(rtx_ctx &s, V3 dir, V3 point, V3 N, const Mat &mt, Stats
         V3 lpos = v3(s.lights[i], s.lights[i + 1], s.lights[i + 2]);
         float intensity = s.lights[i + 3];
         V3 lightDir = normalize(lpos - point);
+        if (s.prune) {
+            // RTX_OPT_PRUNE: a light that can add to neither sum needs no shadow ray (same rule, same
+            // ray counts as the HIP backend; the sums are unchanged)
+            bool lightsPlain = true;
+            for (size_t k = 3; k < s.lights.size(); k += 4) lightsPlain = lightsPlain && s.lights[k] >= 0.0f && s.lights[k] <= 3.0e38f;
+            const bool diffuseCounts = dot(lightDir, N) >= 0 && !(mt.albedo[0] == 0.0f && lightsPlain);
+            if (!diffuseCounts && !(dot(-reflect(-lightDir, N), dir) >= 0)) continue;
+        }
         V3 shadowOrig = std::signbit(dot(lightDir, N)) ? negativeOrig : positiveOrig;
         Hit sh;
         sh.point = v3(0, 0, 0);

@@ -115,7 +115,8 @@ struct DevScene {
     // constants
     float far_clip;  // 700, src/Scene.cpp:57
     float fprec;     // 1e-3, include/Scene.h:23
-    int prune;       // skip children whose weight is exactly 0
+    int prune;       // skip rays whose contribution is exactly nothing (zero-weight children, lights that cannot add)
+    int lights_plain;  // every light intensity is finite and >= 0
 };
 
 // The analytic part of the scene (a few hundred bytes to a few KB) staged in LDS once per block.

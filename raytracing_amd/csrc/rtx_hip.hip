@@ -742,6 +742,9 @@ int rtx_commit(rtx_ctx *c) {
         pad(d.sphere_bounds), pad(d.tri_bounds), pad(d.box_bounds);
     }
 
+    d.lights_plain = 1;
+    for (const float4 &l : c->lights)
+        if (!(l.w >= 0.0f && l.w <= 3.0e38f)) d.lights_plain = 0;
     const int nt = (int)(c->mesh_idx.size() / 3), nv = (int)(c->mesh_verts.size() / 3);
     d.n_mesh_tris = 0;
     if (nt > 0) {

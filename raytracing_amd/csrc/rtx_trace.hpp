@@ -483,12 +483,25 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         st.light = 0;
     }
     if (!returning) {
-        if (st.light < s.n_lights) {
+        while (st.light < s.n_lights) {
             // ---- the next shadow ray, :65-70 ----
             const float4 L = q.lights[st.light];
             const V3 lpos = v3(L.x, L.y, L.z);
             const V3 lightDir = normalize(lpos - st.point);
             st.ndl = dot(lightDir, st.N);
+            if (s.prune) {
+                // A light adds to the diffuse sum only if n.l >= 0 and to the specular sum only if the
+                // mirrored direction faces the viewer (:75-78).  If it can add to neither, its shadow
+                // ray decides nothing and is not cast.  The diffuse sum itself is irrelevant when the
+                // material's diffuse weight is exactly 0 (x * Ld * 0 has the same value for every
+                // finite Ld >= 0, which holds when no light has a negative or non-finite intensity).
+                const bool diffuseCounts = st.ndl >= 0 && !(st.m.a0 == 0.0f && s.lights_plain);
+                const float specIntDot = dot(-reflect(-lightDir, st.N), st.view);
+                if (!diffuseCounts && !(specIntDot >= 0)) {
+                    ++st.light;
+                    continue;
+                }
+            }
             const V3 off = st.N * s.fprec;
             st.orig = __builtin_signbit(st.ndl) ? st.point - off : st.point + off;
             st.dir = lightDir;
