@@ -464,7 +464,12 @@ Lightning calcLightning(rtx_ctx &s, V3 dir, V3 point, V3 N, const Mat &mt, Stats
             bool lightsPlain = true;
             for (size_t k = 3; k < s.lights.size(); k += 4) lightsPlain = lightsPlain && s.lights[k] >= 0.0f && s.lights[k] <= 3.0e38f;
             const bool diffuseCounts = dot(lightDir, N) >= 0 && !(mt.albedo[0] == 0.0f && lightsPlain);
-            if (!diffuseCounts && !(dot(-reflect(-lightDir, N), dir) >= 0)) continue;
+            if (!diffuseCounts) {
+                const float sd = dot(-reflect(-lightDir, N), dir);
+                bool specCounts = sd >= 0;
+                if (specCounts && lightsPlain) specCounts = !(powf(sd, mt.specular) * intensity == 0.0f);
+                if (!specCounts) continue;
+            }
         }
         V3 shadowOrig = std::signbit(dot(lightDir, N)) ? negativeOrig : positiveOrig;
         Hit sh;

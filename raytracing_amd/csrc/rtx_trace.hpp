@@ -495,11 +495,17 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                 // ray decides nothing and is not cast.  The diffuse sum itself is irrelevant when the
                 // material's diffuse weight is exactly 0 (x * Ld * 0 has the same value for every
                 // finite Ld >= 0, which holds when no light has a negative or non-finite intensity).
+                // The specular term itself can be exactly 0 (a high exponent underflows quickly); adding
+                // +0 to a sum of non-negative terms changes nothing either.
                 const bool diffuseCounts = st.ndl >= 0 && !(st.m.a0 == 0.0f && s.lights_plain);
-                const float specIntDot = dot(-reflect(-lightDir, st.N), st.view);
-                if (!diffuseCounts && !(specIntDot >= 0)) {
-                    ++st.light;
-                    continue;
+                if (!diffuseCounts) {
+                    const float specIntDot = dot(-reflect(-lightDir, st.N), st.view);
+                    bool specCounts = specIntDot >= 0;
+                    if (specCounts && s.lights_plain) specCounts = !(refPowf(q.math, specIntDot, st.m.spec) * L.w == 0.0f);
+                    if (!specCounts) {
+                        ++st.light;
+                        continue;
+                    }
                 }
             }
             const V3 off = st.N * s.fprec;

@@ -107,8 +107,8 @@ def test_oracle_ray_counts_match_survey(oracle_backend, textures):
     assert st.shadow_rays == 3965076
     assert st.sky_lookups == 1801692
     # and with pruning (what the GPU traces: no zero-weight children, no shadow rays towards lights that
-    # can add to neither the diffuse nor the specular sum): 757 721 + 1 171 210
+    # can add to neither the diffuse nor the specular sum): 757 721 + 1 120 220
     ctx = make_default_context(oracle_backend, textures, options=[(OPT_STATS, 1), (OPT_PRUNE, 1)])
     _, st = ctx.render(oracle_backend.default_camera(), 800, 600, 4, want_stats=True)
     assert st.primary_rays + st.secondary_rays == 757721
-    assert st.shadow_rays == 1171210
+    assert st.shadow_rays == 1120220
