@@ -94,8 +94,12 @@ typedef struct rtx_stats {
 
 enum rtx_option {
     RTX_OPT_STATS = 1,        /* 0/1: count rays (slower)                                          */
-    RTX_OPT_PRUNE = 2,        /* 0/1 (default 1): skip children whose albedo weight is exactly 0;
-                                 the reference traces them and multiplies by 0 (src/Scene.cpp:95-105) */
+    RTX_OPT_PRUNE = 2,        /* 0/1 (default 1): do not trace rays whose contribution is exactly
+                                 nothing: children whose albedo weight is exactly 0 (the reference
+                                 traces them and multiplies by 0, src/Scene.cpp:95-105) and shadow
+                                 rays towards lights that can add to neither the diffuse nor the
+                                 specular sum (src/Scene.cpp:71-78).  Same pixels as long as all
+                                 colours stay finite (x + 0*c == x needs a finite c)                */
     RTX_OPT_FAR_CLIP = 3,     /* float bits: sceneIntersect's `minDist < 700` (src/Scene.cpp:57)   */
     RTX_OPT_SURFACE_BIAS = 4, /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
     RTX_OPT_BVH_BUILDER = 6,  /* before rtx_commit: 0 (default) = surface-area heuristic on the host

@@ -71,12 +71,13 @@ def kats():
     return dict(np.load(os.path.join(GOLDEN, "kats.npz")))
 
 
-def make_default_context(backend, textures, mask=31, sky="envmap.jpg", options=()):
+def make_default_context(backend, textures, mask=31, sky="envmap.jpg", options=(), commit=True):
     ctx = backend.create()
     ctx.load_default_scene(textures["water"], textures[sky], mask=mask)
     for opt, val in options:
         ctx.set_option(opt, val)
-    ctx.commit()
+    if commit:
+        ctx.commit()
     return ctx
 
 

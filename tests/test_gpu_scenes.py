@@ -162,6 +162,25 @@ def test_empty_scene_and_no_water(hip, oracle_backend, textures):
     assert np.array_equal(frames[0], frames[1])
 
 
+@pytest.mark.parametrize("intensities", [[1.7, 2.0, 1.5], [1.7, -0.5, 1.5], [0.0, 2.0, 1e30]])
+def test_light_pruning_is_exact_for_any_intensities(hip, oracle_backend, textures, intensities):
+    """Shadow rays towards lights that cannot add to the diffuse or the specular sum are skipped
+    (RTX_OPT_PRUNE); negative or non-finite intensities switch the part of the rule that relies on the
+    sums being non-negative off.  Pruned GPU frame == unpruned oracle frame, byte for byte (colours
+    stay finite here: x + 0*c == x, which all pruning rests on, needs a finite c)."""
+    from raytracing_amd.rtx import OPT_PRUNE
+    cam = hip.default_camera()
+    frames = []
+    for b, prune in ((hip, 1), (oracle_backend, 0), (hip, 0)):
+        ctx = make_default_context(b, textures, sky="map.jpg", options=[(OPT_PRUNE, prune)], commit=False)
+        lights = np.array([[-20, 20, 20, intensities[0]], [30, 50, -25, intensities[1]], [30, 20, 30, intensities[2]]], np.float32)
+        ctx.set_lights(lights)
+        ctx.commit()
+        frames.append(ctx.render(cam, 320, 240, 4))
+    assert np.array_equal(frames[0], frames[1])
+    assert np.array_equal(frames[2], frames[1])
+
+
 def test_api_errors(hip, textures):
     ctx = hip.create()
     with pytest.raises(RtxError) as e:
