@@ -106,6 +106,10 @@ enum rtx_option {
                                  for meshes up to 262 144 triangles, Morton order on the GPU above;
                                  1 = always Morton order on the GPU; 2 = always surface-area
                                  heuristic.  The tree only steers the walk: results do not change */
+    RTX_OPT_SCHEDULE_FEEDBACK = 7, /* 0/1 (default 1): the second frame of a view (same camera and
+                                 frame description) starts its tiles in the order of what they
+                                 cost in the first; 0 = always the static order from projected
+                                 bounding boxes.  Scheduling only: pixels do not change             */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:

@@ -83,7 +83,8 @@ constexpr unsigned kQueues = 64, kHeadStride = 32;
 template <bool STATS>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, unsigned *heads,
-                                                   unsigned char *__restrict__ out, Counters *counters) {
+                                                   unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
+                                                   Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
             }
         }
         // ---- trace its 64 paths ----
+        const long long t_tile = wall_clock64();
         while (active) {
             bool hit = false;
             Hit h;
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
                 active = false;
             }
         }
+        // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
+        if (lane == 0) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -311,6 +315,12 @@ struct rtx_ctx {
     unsigned *d_order = nullptr;
     size_t d_order_cap = 0;
     std::vector<unsigned char> order_key;
+    // schedule feedback: per-tile cost of the last frame, and the tile list sorted by it
+    int feedback = 1;                  // RTX_OPT_SCHEDULE_FEEDBACK
+    unsigned *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_order_by_cost = nullptr;
+    void *d_sort_tmp = nullptr;
+    size_t sched_cap = 0, sort_tmp_bytes = 0;
+    std::vector<unsigned char> cost_key, by_cost_key;  // the (camera, frame) those two belong to
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -470,6 +480,32 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
     return RTX_OK;
 }
 
+// Buffers of the schedule feedback, sized for n tiles: cost per tile, the sorted copy, the identity
+// list the sort permutes, the resulting order, and the sort's scratch space.
+int scheduleBuffers(rtx_ctx *c, size_t n) {
+    if (n <= c->sched_cap) return RTX_OK;
+    HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old buffers
+    unsigned **bufs[] = {&c->d_cost, &c->d_cost_sorted, &c->d_iota, &c->d_order_by_cost};
+    for (unsigned **b : bufs) {
+        (void)hipFree(*b);
+        *b = nullptr;
+    }
+    (void)hipFree(c->d_sort_tmp);
+    c->d_sort_tmp = nullptr, c->sched_cap = 0;
+    c->cost_key.clear(), c->by_cost_key.clear();
+    for (unsigned **b : bufs) HIP_OR_FAIL(hipMalloc((void **)b, n * sizeof(unsigned)));
+    std::vector<unsigned> iota(n);
+    for (size_t i = 0; i < n; ++i) iota[i] = (unsigned)i;
+    HIP_OR_FAIL(hipMemcpy(c->d_iota, iota.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIP_OR_FAIL(hipMemset(c->d_cost, 0, n * sizeof(unsigned)));
+    c->sort_tmp_bytes = 0;
+    HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
+                                                             c->d_order_by_cost, (int)n, 0, 32, nullptr));
+    HIP_OR_FAIL(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
+    c->sched_cap = n;
+    return RTX_OK;
+}
+
 // enqueue one render on `stream`; output rows * width * 3 bytes at d_out.  The queue heads, the
 // counters and the timing events belong to the context: one render of a context at a time.
 int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
@@ -482,7 +518,23 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     DevScene s = c->dev;
     s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
     const unsigned *order = nullptr;
-    if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order)) return e;
+    if (int e = scheduleBuffers(c, (size_t)n_tiles)) return e;
+    std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame));
+    memcpy(key.data(), cam, sizeof(rtx_camera));
+    memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
+    // Longest tiles first.  The first frame of a view goes by classes from projected bounding boxes
+    // (tileOrder); every frame records what each tile cost, and the second frame of the same view
+    // sorts the tiles by that, on the device and in stream order (one radix sort, about as long as
+    // 3 % of a 4K frame), after which the list is kept until the view changes.
+    bool sort_now = false;
+    if (c->feedback && key == c->by_cost_key) {
+        order = c->d_order_by_cost;
+    } else if (c->feedback && key == c->cost_key) {
+        order = c->d_order_by_cost;
+        sort_now = true;
+    } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order)) {
+        return e;
+    }
     // blocks that are resident at once: the kernel is a loop over tiles, more blocks would only queue
     int &resident = c->resident_blocks[c->stats ? 1 : 0];
     if (resident == 0) {
@@ -498,13 +550,19 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
+    if (sort_now) {
+        HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(c->d_sort_tmp, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
+                                                                 c->d_order_by_cost, (int)n_tiles, 0, 32, stream));
+        c->by_cost_key = key;
+    }
     if (c->stats)
         hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, c->d_heads, d_out, c->d_counters);
+                           (unsigned)n_tiles, order, c->d_heads, c->d_cost, d_out, c->d_counters);
     else
         hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, c->d_heads, d_out, c->d_counters);
+                           (unsigned)n_tiles, order, c->d_heads, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
+    c->cost_key = key;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return RTX_OK;
@@ -546,6 +604,11 @@ void rtx_destroy(rtx_ctx *c) {
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_heads);
     (void)hipFree(c->d_order);
+    (void)hipFree(c->d_cost);
+    (void)hipFree(c->d_cost_sorted);
+    (void)hipFree(c->d_iota);
+    (void)hipFree(c->d_order_by_cost);
+    (void)hipFree(c->d_sort_tmp);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -562,6 +625,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_PRUNE: c->prune = value != 0; break;
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
+        case RTX_OPT_SCHEDULE_FEEDBACK: c->feedback = value != 0; break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
             if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 auto, 1 Morton order on the GPU, 2 surface-area heuristic on the host");
