@@ -99,6 +99,8 @@ struct DevScene {
     // conservative bounds of whole categories (lo xyz, hi xyz), padded: a ray that misses one
     // cannot hit anything inside, so the exact per-primitive tests are skipped for it
     float sphere_bounds[6], tri_bounds[6], box_bounds[6];
+    float object_bounds[6];  // union of the three and the mesh gate box
+    float island_rect[4];    // x min, x max, z min, z max over all islands, padded
     // islands
     const float4 *islands;  // cx, cz, a, b
     int n_islands;

@@ -866,6 +866,32 @@ int rtx_commit(rtx_ctx *c) {
             d.grid_fast_tmax = (min_step > 0.0f && max_abs < 500.0f * min_step) ? 500.0f * min_step : 0.0f;
         }
     }
+    {  // union of everything that is tested against a box, and the rectangle around the islands
+        float *u = d.object_bounds;
+        for (int k = 0; k < 3; ++k) u[k] = 3.0e38f, u[3 + k] = -3.0e38f;
+        auto join = [&](const float *lo, const float *hi) {
+            for (int k = 0; k < 3; ++k) u[k] = std::fmin(u[k], lo[k]), u[3 + k] = std::fmax(u[3 + k], hi[k]);
+        };
+        if (!c->spheres.empty()) join(d.sphere_bounds, d.sphere_bounds + 3);
+        if (!c->tris.empty()) join(d.tri_bounds, d.tri_bounds + 3);
+        if (!c->boxes.empty()) join(d.box_bounds, d.box_bounds + 3);
+        if (d.n_mesh_tris > 0) {
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) {
+                const float e = 1e-4f * (d.mesh_hi[k] - d.mesh_lo[k]) + 1e-5f * std::fmax(std::fabs(d.mesh_lo[k]), std::fabs(d.mesh_hi[k])) + 1e-6f;
+                lo[k] = d.mesh_lo[k] - e, hi[k] = d.mesh_hi[k] + e;
+            }
+            join(lo, hi);
+        }
+        float *r = d.island_rect;
+        r[0] = r[2] = 3.0e38f, r[1] = r[3] = -3.0e38f;
+        for (const float4 &is : c->islands) {  // cx, cz, a, b: the reference's own rectangle is cx -+ a, cz -+ b
+            const float a = std::fabs(is.z), b = std::fabs(is.w);
+            const float ex = 1e-4f * a + 1e-5f * std::fabs(is.x) + 1e-6f, ez = 1e-4f * b + 1e-5f * std::fabs(is.y) + 1e-6f;
+            r[0] = std::fmin(r[0], is.x - a - ex), r[1] = std::fmax(r[1], is.x + a + ex);
+            r[2] = std::fmin(r[2], is.y - b - ez), r[3] = std::fmax(r[3], is.y + b + ez);
+        }
+    }
     c->committed = true;
     // host copies are no longer needed
     std::vector<unsigned char>().swap(c->sky);

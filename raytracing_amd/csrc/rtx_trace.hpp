@@ -211,6 +211,9 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     float minDist = kFltMax;
     int kind = 0, index = -1;
     const V3 inv = safeInverse(dir);
+    cs.minDist = minDist, cs.kind = kind, cs.index = index;
+    // one filter for everything that has a bounding box: most rays of an open scene miss it all
+    if (!slabMaybe(s.object_bounds, s.object_bounds + 3, orig, inv)) return false;
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
     if (s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
@@ -289,7 +292,9 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
         if (s.n_islands > 0 && planeHit(s.island_y, orig, dir, dist)) {
             RTX_COUNT_N(CNT_ISLAND_TESTS, s.n_islands);
             const V3 pt = orig + dir * dist;
-            for (int i = 0; i < s.n_islands; ++i) {
+            // the rectangle around all islands first (padded; the exact conditions follow per island)
+            const bool near_islands = pt.x > s.island_rect[0] && pt.x < s.island_rect[1] && pt.z > s.island_rect[2] && pt.z < s.island_rect[3];
+            for (int i = 0; near_islands && i < s.n_islands; ++i) {
                 const float4 is = q.islands[i];  // cx, cz, a, b
                 // the bounding-rectangle conditions come first in the reference's && chain as well; the
                 // two divisions of the ellipse test are only paid inside the rectangle
