@@ -110,6 +110,10 @@ enum rtx_option {
                                  frame description) starts its tiles in the order of what they
                                  cost in the first; 0 = always the static order from projected
                                  bounding boxes.  Scheduling only: pixels do not change             */
+    RTX_OPT_QUAD = 8,         /* 0/1/2 (default 1): with schedule feedback, tiles that lasted long in
+                                 the previous frame of the view are traced with four lanes per pixel
+                                 (the shadow rays of a node go out side by side): 0 never, 1 the tiles
+                                 that would hold the frame up, 2 every tile.  Pixels do not change   */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:

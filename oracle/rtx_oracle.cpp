@@ -588,6 +588,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_MESH_GRID: c->mesh_grid = value != 0; break;
         case RTX_OPT_BVH_BUILDER: break;  // no tree here
         case RTX_OPT_SCHEDULE_FEEDBACK: break;  // no tile schedule here
+        case RTX_OPT_QUAD: break;
         default: return fail(RTX_E_INVALID, "unknown option");
     }
     return RTX_OK;

@@ -79,10 +79,77 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
 // mixes rays of different screen regions in one wave, and the loss of coherence (more divergent
 // category tests, longer mesh walks) costs more than the idle lanes do.
 constexpr unsigned kQueues = 64, kHeadStride = 32;
+constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
+
+// After the tiles have been sorted by last frame's cost: those that lasted longer than a share
+// (kQuadShare) of what the whole frame would take if its work were spread evenly over all wave slots
+// -- the ones that would hold the frame up -- are entered as four quarters in quad mode, all others
+// once.  Never fewer ticks than min_ticks, never more than `cap` tiles.  out must hold n + 3 * cap
+// entries; *n_out receives the count.
+constexpr float kQuadShare = 0.6f;
+__global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const unsigned *__restrict__ tiles_sorted, unsigned n,
+                               unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap, unsigned *__restrict__ out,
+                               unsigned *__restrict__ n_out) {
+    __shared__ unsigned long long s_sum[256];
+    __shared__ unsigned s_heavy;
+    unsigned long long sum = 0;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) sum += cost_sorted[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned off = blockDim.x / 2u; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float even = (float)s_sum[0] / (float)(wave_slots ? wave_slots : 1u);
+        const float share = quad_share * even;
+        const unsigned limit = share > (float)min_ticks ? (unsigned)share : min_ticks;
+        unsigned lo = 0, hi = n;  // first index whose cost is below the limit (costs descend)
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) / 2u;
+            if (cost_sorted[mid] >= limit) lo = mid + 1u;
+            else hi = mid;
+        }
+        s_heavy = lo < cap ? lo : cap;
+    }
+    __syncthreads();
+    const unsigned heavy = s_heavy;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n + 3u * heavy;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned t = tiles_sorted[i];
+        if (i < heavy) {
+            for (unsigned sub = 0; sub < 4u; ++sub) out[4u * i + sub] = t | (sub << 28) | kQuadFlag;
+        } else {
+            out[3u * heavy + i] = t;
+        }
+    }
+}
+
+// Advances the lane's path, one ray per trip, until it is complete; the pixel's B,G,R bytes
+// (include/bitmap_image.hpp:207-209) go to `bgr` (the wave's tile buffer in LDS).
+template <bool STATS>
+__device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool active,
+                                           const int quad_j, unsigned char *bgr, int *stack, LaneCounters<STATS> &lc) {
+    while (active) {
+        bool hit = false;
+        Hit h;
+        float md = 0.0f;
+        if (pathCasts(st, quad_j)) {
+            pathCountRay<STATS>(st, quad_j, lc);
+            hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
+        }
+        V3 c;
+        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
+            if (quad_j <= 0) bgr[0] = toByte(c.z), bgr[1] = toByte(c.y), bgr[2] = toByte(c.x);
+            active = false;
+        }
+    }
+}
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
-                                                   const unsigned *__restrict__ order, unsigned *heads,
+                                                   const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
+                                                   unsigned *heads,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
                                                    Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
@@ -95,7 +162,9 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     // rows of whole dwords: a finished tile goes out as 48 dword stores instead of 192 byte stores
     const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
-    const unsigned my_len = lane < n_tiles ? (n_tiles - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
+    // the list has one entry per tile, or four for a tile that is traced in quad mode (see kQuadFlag)
+    const unsigned n_entries = n_entries_dev ? *n_entries_dev : n_tiles;
+    const unsigned my_len = lane < n_entries ? (n_entries - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
     unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
     LaneCounters<STATS> lc;
     PathState st;
@@ -124,51 +193,51 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
             qi = (unsigned)__builtin_ctzll(after ? after : live);
         }
         if (tile == 0xffffffffu) break;  // every queue is empty
-        const int x0 = (int)(tile % tiles_x) * 8, y0 = (int)(tile / tiles_x) * 8;
+        // An entry with kQuadFlag is a quarter (4x4 pixels, bits 28-29 say which) of a tile that lasted
+        // long in the previous frame: four lanes share a pixel (quad mode of pathConsume).
+        const bool quad = (tile & kQuadFlag) != 0u;
+        const unsigned sub = (tile >> 28) & 3u;
+        tile &= kTileMask;
+        const int quad_j = quad ? (int)(lane & 3u) : -1;
+        const unsigned pix = quad ? lane >> 2 : lane;  // pixel of the (sub-)tile this lane works on
+        const int side = quad ? 4 : 8;
+        const unsigned side_shift = quad ? 2u : 3u;
+        const int x0 = (int)(tile % tiles_x) * 8 + (quad ? (int)(sub & 1u) * 4 : 0);
+        const int y0 = (int)(tile / tiles_x) * 8 + (quad ? (int)(sub >> 1) * 4 : 0);
         bool active;
         {
-            const int px = x0 + (int)(lane & 7u), pk = y0 + (int)(lane >> 3);
+            const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
             active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
             if (active) {
                 const int row = fr.row_first + pk * fr.row_step;
                 pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
             }
         }
-        // ---- trace its 64 paths ----
+        // ---- trace its paths ----
         const long long t_tile = wall_clock64();
-        while (active) {
-            bool hit = false;
-            Hit h;
-            float md = 0.0f;
-            if (pathCasts(st)) {
-                pathCountRay<STATS>(st, lc);
-                hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
-            }
-            V3 c;
-            if (pathConsume<STATS>(s, q, st, frames, hit, h, md, c, lc)) {
-                unsigned char *p = &s_tile[threadIdx.x >> 6][3 * lane];
-                p[0] = toByte(c.z), p[1] = toByte(c.y), p[2] = toByte(c.x);  // B, G, R: include/bitmap_image.hpp:207-209
-                active = false;
-            }
-        }
+        // two copies of the loop, one per mode: in the common one quad_j is the constant -1 and the quad
+        // logic folds away
+        if (quad) tracePaths<STATS>(s, q, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
+        else tracePaths<STATS>(s, q, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
-        if (lane == 0) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile);
+        if (lane == 0 && !quad) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (dword_rows && x0 + 8 <= fr.width && y0 + 8 <= fr.rows) {
-            // 8 rows of 24 bytes = 48 dword stores instead of 192 byte stores
-            if (lane < 48u) {
-                const unsigned r = lane / 6u, w = lane % 6u;
+        if (dword_rows && x0 + side <= fr.width && y0 + side <= fr.rows) {
+            // rows of 24 (12) bytes: 48 (12) dword stores instead of 192 (48) byte stores
+            const unsigned row_dwords = quad ? 3u : 6u;
+            if (lane < row_dwords * (unsigned)side) {
+                const unsigned r = lane / row_dwords, w = lane % row_dwords;
                 unsigned *dst = reinterpret_cast<unsigned *>(out + ((size_t)(y0 + (int)r) * fr.width + x0) * 3) + w;
                 *dst = *reinterpret_cast<const unsigned *>(&s_tile[threadIdx.x >> 6][4 * lane]);
             }
-        } else {
-            const int px = x0 + (int)(lane & 7u), pk = y0 + (int)(lane >> 3);
+        } else if (quad_j <= 0) {
+            const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
             if (px < fr.width && pk < fr.rows) {
-                const unsigned char *src = &s_tile[threadIdx.x >> 6][3 * lane];
+                const unsigned char *src = &s_tile[threadIdx.x >> 6][3 * pix];
                 unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
                 p[0] = src[0], p[1] = src[1], p[2] = src[2];
             }
@@ -317,7 +386,9 @@ struct rtx_ctx {
     std::vector<unsigned char> order_key;
     // schedule feedback: per-tile cost of the last frame, and the tile list sorted by it
     int feedback = 1;                  // RTX_OPT_SCHEDULE_FEEDBACK
+    int quad_mode = 1;                 // RTX_OPT_QUAD
     unsigned *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_order_by_cost = nullptr;
+    unsigned *d_entries = nullptr;     // d_order_by_cost with the longest tiles split into quarters; [cap] = entry count
     void *d_sort_tmp = nullptr;
     size_t sched_cap = 0, sort_tmp_bytes = 0;
     std::vector<unsigned char> cost_key, by_cost_key;  // the (camera, frame) those two belong to
@@ -491,9 +562,11 @@ int scheduleBuffers(rtx_ctx *c, size_t n) {
         *b = nullptr;
     }
     (void)hipFree(c->d_sort_tmp);
-    c->d_sort_tmp = nullptr, c->sched_cap = 0;
+    (void)hipFree(c->d_entries);
+    c->d_sort_tmp = nullptr, c->d_entries = nullptr, c->sched_cap = 0;
     c->cost_key.clear(), c->by_cost_key.clear();
     for (unsigned **b : bufs) HIP_OR_FAIL(hipMalloc((void **)b, n * sizeof(unsigned)));
+    HIP_OR_FAIL(hipMalloc((void **)&c->d_entries, (4 * n + 1) * sizeof(unsigned)));
     std::vector<unsigned> iota(n);
     for (size_t i = 0; i < n; ++i) iota[i] = (unsigned)i;
     HIP_OR_FAIL(hipMemcpy(c->d_iota, iota.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -514,7 +587,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows};
     const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
     const long long n_tiles = (long long)tiles_x * tiles_y;
-    if (n_tiles > 0x7fffffffLL) return fail(RTX_E_LIMIT, "frame too large for one launch");
+    if (n_tiles > (long long)kTileMask) return fail(RTX_E_LIMIT, "frame too large for one launch");
     DevScene s = c->dev;
     s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
     const unsigned *order = nullptr;
@@ -527,10 +600,12 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     // sorts the tiles by that, on the device and in stream order (one radix sort, about as long as
     // 3 % of a 4K frame), after which the list is kept until the view changes.
     bool sort_now = false;
+    const unsigned *n_entries_dev = nullptr;
+    unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;
     if (c->feedback && key == c->by_cost_key) {
-        order = c->d_order_by_cost;
+        order = c->d_entries, n_entries_dev = d_n_entries;
     } else if (c->feedback && key == c->cost_key) {
-        order = c->d_order_by_cost;
+        order = c->d_entries, n_entries_dev = d_n_entries;
         sort_now = true;
     } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order)) {
         return e;
@@ -545,22 +620,31 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         else HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<false>, kBlock, 0));
         resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
     }
-    const long long want = (n_tiles + kBlock / 64 - 1) / (kBlock / 64);
+    const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
     if (sort_now) {
+        // by cost in units of 2^11 ticks (20 us); the sort is stable, so the many cheap tiles keep their
+        // raster order and with it the locality of their texture fetches
         HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(c->d_sort_tmp, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
                                                                  c->d_order_by_cost, (int)n_tiles, 0, 32, stream));
+        // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.1 ms,
+        // never more than an eighth of all), 2 every tile
+        const unsigned cap = c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
+        hipLaunchKernelGGL(k_expand_order, dim3(64), dim3(256), 0, stream, c->d_cost_sorted, c->d_order_by_cost, (unsigned)n_tiles,
+                           (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 10000u, cap,
+                           c->d_entries, d_n_entries);
+        HIP_OR_FAIL(hipGetLastError());
         c->by_cost_key = key;
     }
     if (c->stats)
         hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, c->d_heads, c->d_cost, d_out, c->d_counters);
+                           (unsigned)n_tiles, order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
     else
         hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, c->d_heads, c->d_cost, d_out, c->d_counters);
+                           (unsigned)n_tiles, order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
     c->cost_key = key;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
@@ -608,6 +692,7 @@ void rtx_destroy(rtx_ctx *c) {
     (void)hipFree(c->d_cost_sorted);
     (void)hipFree(c->d_iota);
     (void)hipFree(c->d_order_by_cost);
+    (void)hipFree(c->d_entries);
     (void)hipFree(c->d_sort_tmp);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -626,6 +711,11 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_FAR_CLIP: c->far_clip = f; break;
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
         case RTX_OPT_SCHEDULE_FEEDBACK: c->feedback = value != 0; break;
+        case RTX_OPT_QUAD:
+            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD: 0 never, 1 automatic, 2 every tile");
+            c->quad_mode = (int)value;
+            c->by_cost_key.clear();  // the entry list is rebuilt with the next frame
+            break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
             if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 auto, 1 Morton order on the GPU, 2 surface-area heuristic on the host");

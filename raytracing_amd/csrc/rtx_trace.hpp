@@ -431,24 +431,104 @@ struct PathState {
     V3 point, N, view;
     Material m;
     float ndl, lightDist, Ld, Ls;
+    int cast_mask;  // quad mode: which lights of the current batch of four get a shadow ray
 };
 
 RTX_DEV void pathStart(PathState &st, V3 orig, V3 dir, int depth) {
     st.orig = orig, st.dir = dir, st.depth = depth, st.fullDepth = depth, st.sp = 0;
-    st.light = -1, st.t_exit = -1.0f;
+    st.light = -1, st.t_exit = -1.0f, st.cast_mask = 0;
 }
 
-// Does the pending ray have to be cast at all?  (A closest-hit ray of depth 0 is answered by the sky.)
-RTX_DEV bool pathCasts(const PathState &st) { return st.light >= 0 || st.depth > 0; }
+// Quad mode.  Four neighbouring lanes (a "quad") can share ONE pixel: all four hold the same path
+// state and cast the same closest-hit rays, but the shadow rays of a node go out four lights at a
+// time, one per lane, and the verdicts are exchanged with DPP.  A node then takes two casts instead
+// of one plus one per light, which halves the longest chains of the frame at the price of three
+// redundant lanes; the kernel uses it for the few tiles that last longest.  quad_j is the lane's
+// place in its quad (0..3), or -1 in the normal one-pixel-per-lane mode.
+
+// Does the pending ray have to be cast at all?  (A closest-hit ray of depth 0 is answered by the
+// sky; in quad mode a lane casts only its own light of the batch.)
+RTX_DEV bool pathCasts(const PathState &st, int quad_j) {
+    if (st.light >= 0) return quad_j < 0 || ((st.cast_mask >> quad_j) & 1);
+    return st.depth > 0;
+}
 
 template <bool STATS>
-RTX_DEV void pathCountRay(const PathState &st, LaneCounters<STATS> &lc) {
+RTX_DEV void pathCountRay(const PathState &st, int quad_j, LaneCounters<STATS> &lc) {
     if constexpr (STATS) {
         const bool shadow = st.light >= 0;
+        const bool first = quad_j <= 0;  // the four lanes of a quad cast the same closest-hit ray: count it once
         lc.v[CNT_SHADOW] += shadow ? 1u : 0u;
-        lc.v[CNT_PRIMARY] += !shadow && st.depth == st.fullDepth ? 1u : 0u;
-        lc.v[CNT_SECONDARY] += !shadow && st.depth != st.fullDepth ? 1u : 0u;
+        lc.v[CNT_PRIMARY] += !shadow && first && st.depth == st.fullDepth ? 1u : 0u;
+        lc.v[CNT_SECONDARY] += !shadow && first && st.depth != st.fullDepth ? 1u : 0u;
     }
+}
+
+// One light of calcLightning, src/Scene.cpp:64-79, in three pieces.
+struct LightAim {
+    V3 pos, dir;  // the light, the unit vector towards it
+    float ndl, intensity;
+    bool counts;  // false: the light can add to neither sum, its shadow ray decides nothing
+};
+
+RTX_DEV LightAim aimLight(const DevScene &s, const SmallScene &q, const PathState &st, int li) {
+    LightAim a;
+    const float4 L = q.lights[li];
+    a.pos = v3(L.x, L.y, L.z);
+    a.intensity = L.w;
+    a.dir = normalize(a.pos - st.point);
+    a.ndl = dot(a.dir, st.N);
+    a.counts = true;
+    if (s.prune) {
+        // A light adds to the diffuse sum only if n.l >= 0 and to the specular sum only if the
+        // mirrored direction faces the viewer (:75-78).  If it can add to neither, its shadow ray
+        // decides nothing and is not cast.  The diffuse sum itself is irrelevant when the
+        // material's diffuse weight is exactly 0 (x * Ld * 0 has the same value for every finite
+        // Ld >= 0, which holds when no light has a negative or non-finite intensity).  The
+        // specular term itself can be exactly 0 (a high exponent underflows quickly); adding +0 to
+        // a sum of non-negative terms changes nothing either.
+        const bool diffuseCounts = a.ndl >= 0 && !(st.m.a0 == 0.0f && s.lights_plain);
+        if (!diffuseCounts) {
+            const float specIntDot = dot(-reflect(-a.dir, st.N), st.view);
+            bool specCounts = specIntDot >= 0;
+            if (specCounts && s.lights_plain) specCounts = !(refPowf(q.math, specIntDot, st.m.spec) * a.intensity == 0.0f);
+            a.counts = specCounts;
+        }
+    }
+    return a;
+}
+
+// the shadow ray towards an aimed light becomes the pending ray, :65-70
+RTX_DEV void pathAimShadowRay(const DevScene &s, PathState &st, const LightAim &a) {
+    const V3 off = st.N * s.fprec;
+    st.ndl = a.ndl;
+    st.orig = __builtin_signbit(a.ndl) ? st.point - off : st.point + off;
+    st.dir = a.dir;
+    st.lightDist = distance(a.pos, st.point);
+    // A hit nearer than this decides the reference's test for certain: the closest hit is then at
+    // least that near, and |orig + dir*t - orig| differs from t by a few ulp only.
+    st.t_exit = fminf(st.lightDist * 0.999f, s.far_clip);
+}
+
+// :71-72: is the pending shadow ray's light hidden?
+RTX_DEV bool pathShadowed(const PathState &st, bool hit, float md) {
+    if (!hit) return false;
+    if (md < st.t_exit) return true;
+    const V3 shadowPt = st.orig + st.dir * md;
+    return distance(shadowPt, st.orig) < st.lightDist;
+}
+
+// :74-78: an unhidden light's share of the two sums
+RTX_DEV void pathAddLight(const SmallScene &q, PathState &st, V3 lightDir, float ndl, float intensity) {
+    if (ndl >= 0) st.Ld += intensity * ndl;
+    const float specIntDot = dot(-reflect(-lightDir, st.N), st.view);
+    if (specIntDot >= 0) st.Ls += refPowf(q.math, specIntDot, st.m.spec) * intensity;
+}
+
+// value of lane k of the caller's quad
+template <int k>
+RTX_DEV int quadBroadcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, k | (k << 2) | (k << 4) | (k << 6), 0xf, 0xf, true);
 }
 
 // Consumes the result of the pending ray (hit, h, md: what castEnd returned; hit = false when the ray
@@ -456,30 +536,35 @@ RTX_DEV void pathCountRay(const PathState &st, LaneCounters<STATS> &lc) {
 // then the value traceRay would have returned.
 template <bool STATS>
 RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool hit, const Hit &h, float md,
-                         V3 &color, LaneCounters<STATS> &lc) {
+                         int quad_j, V3 &color, LaneCounters<STATS> &lc) {
     const bool shadow = st.light >= 0;
-    bool returning = false;  // `color` holds the finished value of a node
-    if (shadow) {
-        // ---- one light of calcLightning, :64-79, after its shadow ray ----
-        bool occluded = false;
-        if (hit) {
-            if (md < st.t_exit) {
-                occluded = true;
-            } else {
-                const V3 shadowPt = st.orig + st.dir * md;
-                occluded = distance(shadowPt, st.orig) < st.lightDist;
-            }
-        }
-        if (!occluded) {
+    const bool count = quad_j <= 0;  // statistics: once per pixel
+    bool returning = false;          // `color` holds the finished value of a node
+    if (shadow && quad_j < 0) {
+        // ---- after the shadow ray of light st.light ----
+        if (!pathShadowed(st, hit, md)) {
             RTX_COUNT(CNT_LIT);
-            const float intensity = q.lights[st.light].w;
-            if (st.ndl >= 0) st.Ld += intensity * st.ndl;
-            const float specIntDot = dot(-reflect(-st.dir, st.N), st.view);
-            if (specIntDot >= 0) st.Ls += refPowf(q.math, specIntDot, st.m.spec) * intensity;
+            pathAddLight(q, st, st.dir, st.ndl, q.lights[st.light].w);
         }
         ++st.light;
+    } else if (shadow) {
+        // ---- quad mode: after the shadow rays of lights st.light .. st.light + 3, one per lane.  Every
+        // lane of the quad adds all of them up, in the reference's order, so the four states stay equal.
+        const int mine = ((st.cast_mask >> quad_j) & 1) && pathShadowed(st, hit, md) ? 1 : 0;
+        const int hidden[4] = {quadBroadcast<0>(mine), quadBroadcast<1>(mine), quadBroadcast<2>(mine), quadBroadcast<3>(mine)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int li = st.light + k;
+            if (li < s.n_lights && ((st.cast_mask >> k) & 1) && !hidden[k]) {
+                if constexpr (STATS) lc.v[CNT_LIT] += count ? 1u : 0u;
+                const float4 L = q.lights[li];
+                const V3 lightDir = normalize(v3(L.x, L.y, L.z) - st.point);
+                pathAddLight(q, st, lightDir, dot(lightDir, st.N), L.w);
+            }
+        }
+        st.light += 4;
     } else if (!hit) {
-        RTX_COUNT(CNT_SKY);
+        if constexpr (STATS) lc.v[CNT_SKY] += count ? 1u : 0u;
         color = skyColor(s, st.dir);
         returning = true;
     } else {
@@ -488,39 +573,33 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         st.light = 0;
     }
     if (!returning) {
+        // ---- the next shadow ray(s) ----
         while (st.light < s.n_lights) {
-            // ---- the next shadow ray, :65-70 ----
-            const float4 L = q.lights[st.light];
-            const V3 lpos = v3(L.x, L.y, L.z);
-            const V3 lightDir = normalize(lpos - st.point);
-            st.ndl = dot(lightDir, st.N);
-            if (s.prune) {
-                // A light adds to the diffuse sum only if n.l >= 0 and to the specular sum only if the
-                // mirrored direction faces the viewer (:75-78).  If it can add to neither, its shadow
-                // ray decides nothing and is not cast.  The diffuse sum itself is irrelevant when the
-                // material's diffuse weight is exactly 0 (x * Ld * 0 has the same value for every
-                // finite Ld >= 0, which holds when no light has a negative or non-finite intensity).
-                // The specular term itself can be exactly 0 (a high exponent underflows quickly); adding
-                // +0 to a sum of non-negative terms changes nothing either.
-                const bool diffuseCounts = st.ndl >= 0 && !(st.m.a0 == 0.0f && s.lights_plain);
-                if (!diffuseCounts) {
-                    const float specIntDot = dot(-reflect(-lightDir, st.N), st.view);
-                    bool specCounts = specIntDot >= 0;
-                    if (specCounts && s.lights_plain) specCounts = !(refPowf(q.math, specIntDot, st.m.spec) * L.w == 0.0f);
-                    if (!specCounts) {
-                        ++st.light;
-                        continue;
+            if (quad_j < 0) {
+                const LightAim a = aimLight(s, q, st, st.light);
+                if (!a.counts) {
+                    ++st.light;
+                    continue;
+                }
+                pathAimShadowRay(s, st, a);
+                return false;
+            }
+            int mask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (st.light + k < s.n_lights) {
+                    const LightAim a = aimLight(s, q, st, st.light + k);
+                    if (a.counts) {
+                        mask |= 1 << k;
+                        if (k == quad_j) pathAimShadowRay(s, st, a);
                     }
                 }
             }
-            const V3 off = st.N * s.fprec;
-            st.orig = __builtin_signbit(st.ndl) ? st.point - off : st.point + off;
-            st.dir = lightDir;
-            st.lightDist = distance(lpos, st.point);
-            // A hit nearer than this decides the reference's test for certain: the closest hit is
-            // then at least that near, and |orig + dir*t - orig| differs from t by a few ulp only.
-            st.t_exit = fminf(st.lightDist * 0.999f, s.far_clip);
-            return false;
+            if (mask) {
+                st.cast_mask = mask;
+                return false;
+            }
+            st.light += 4;
         }
         // ---- all lights done: the node's own colour and its children, :96-105 ----
         st.light = -1, st.t_exit = -1.0f;
@@ -542,11 +621,11 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                 // once (src/Scene.cpp:87-88), so they are evaluated in place
                 V3 c = base;
                 if (doRefl) {
-                    RTX_COUNT(CNT_SKY);
+                    if constexpr (STATS) lc.v[CNT_SKY] += count ? 1u : 0u;
                     c = c + skyColor(s, reflD) * m.a2;
                 }
                 if (doRefr) {
-                    RTX_COUNT(CNT_SKY);
+                    if constexpr (STATS) lc.v[CNT_SKY] += count ? 1u : 0u;
                     c = c + skyColor(s, refrD) * m.a3;
                 }
                 color = c;
@@ -602,11 +681,11 @@ RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int
         bool hit = false;
         Hit h;
         float md = 0.0f;
-        if (pathCasts(st)) {
-            pathCountRay<STATS>(st, lc);
+        if (pathCasts(st, -1)) {
+            pathCountRay<STATS>(st, -1, lc);
             hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
         }
-        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, color, lc)) return color;
+        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, -1, color, lc)) return color;
     }
 }
 
