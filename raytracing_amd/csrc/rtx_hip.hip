@@ -86,7 +86,7 @@ constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
 // -- the ones that would hold the frame up -- are entered as four quarters in quad mode, all others
 // once.  Never fewer ticks than min_ticks, never more than `cap` tiles.  out must hold n + 3 * cap
 // entries; *n_out receives the count.
-constexpr float kQuadShare = 0.6f;
+constexpr float kQuadShare = 0.8f;
 __global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const unsigned *__restrict__ tiles_sorted, unsigned n,
                                unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap, unsigned *__restrict__ out,
                                unsigned *__restrict__ n_out) {
