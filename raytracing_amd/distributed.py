@@ -32,8 +32,8 @@ class ShardedRenderer:
     """Renders row-interleaved shares of a frame and gathers them on rank 0.
 
     ctx: a committed raytracing_amd Context on this rank's GPU.  `process_group` None = single GPU
-    (no communication at all).  Buffers are allocated once; render() enqueues on torch's current
-    stream and returns the assembled frame tensor on rank 0 (None elsewhere).
+    (no communication at all).  Buffers are allocated once; render() enqueues on the renderer's own
+    streams and returns the assembled frame tensor on rank 0 (None elsewhere).
     """
 
     def __init__(self, ctx, width, height, depth, rank=0, world_size=1, device=None, n_buffers=2):
@@ -52,50 +52,65 @@ class ShardedRenderer:
             self.gathered = [torch.zeros(world_size * self.rpr * row_bytes, dtype=torch.uint8, device=self.device)
                              for _ in range(n_buffers)]
             self.frames = [torch.zeros(height * row_bytes, dtype=torch.uint8, device=self.device) for _ in range(n_buffers)]
-        self.pending = [None] * n_buffers
+        self.pending = [None] * n_buffers   # ranks > 0: the gather that still reads local[k]
+        self.released = [None] * n_buffers  # rank 0: event after which local[k] / gathered[k] / frames[k] may be reused
         self.step = 0
-        # A stream of our own: rtx_render_device treats a NULL stream as "the context's stream", and
-        # torch's default stream IS the NULL stream, so the render, the collective and the
-        # de-interleave are all issued on this explicit one (NCCL work is ordered after the
-        # current stream at the time of the call).
+        # Streams of our own: rtx_render_device treats a NULL stream as "the context's stream", and
+        # torch's default stream IS the NULL stream.  Renders go to `stream`; the collective and the
+        # de-interleave go to `comm`, which waits for the render it ships, so that the exchange of
+        # frame k runs while frame k+1 is being rendered (buffers are double).
         self.stream = torch.cuda.Stream(self.device)
+        self.comm = torch.cuda.Stream(self.device)
 
     def render(self, cam):
         """One frame.  Enqueues the render of this rank's rows, the gather and (rank 0) the
-        de-interleave.  Returns (frame_tensor_or_None, work_handle_or_None)."""
-        with self.torch.cuda.stream(self.stream):
-            return self._render(cam)
-
-    def _render(self, cam):
+        de-interleave.  Returns (frame_tensor_or_None, work_handle_or_None); the frame is complete once
+        finish() has been called (or the `comm` stream has been waited for)."""
+        torch = self.torch
         k = self.step % len(self.local)
         self.step += 1
-        stream = self.stream
-        if self.pending[k] is not None:  # the buffer's previous gather must have drained
-            self.pending[k].wait()
-            self.pending[k] = None
-        self.ctx.render_device(cam, self.frame_desc, self.local[k].data_ptr(), stream.cuda_stream)
-        if self.world == 1:
-            return self.local[k], None
+        with torch.cuda.stream(self.stream):
+            # the buffer's previous exchange must have drained before it is rendered into again
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+            if self.released[k] is not None:
+                self.stream.wait_event(self.released[k])
+                self.released[k] = None
+            self.ctx.render_device(cam, self.frame_desc, self.local[k].data_ptr(), self.stream.cuda_stream)
+            if self.world == 1:
+                return self.local[k], None
+            rendered = torch.cuda.Event()
+            rendered.record(self.stream)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(rendered)  # NCCL work is ordered after the current stream at the time of the call
+            if self.rank == 0:
+                chunks = list(self.gathered[k].chunk(self.world))
+                work = self._gather(self.local[k], chunks)
+                work.wait()  # orders `comm` after the gather; does not block the host
+                self.ctx.deinterleave_device(self.gathered[k].data_ptr(), self.world, self.rpr, self.width, self.height,
+                                             self.frames[k].data_ptr(), self.comm.cuda_stream)
+                self.released[k] = torch.cuda.Event()
+                self.released[k].record(self.comm)
+                return self.frames[k], None
+            work = self._gather(self.local[k], None)
+            self.pending[k] = work
+            return None, work
+
+    def _gather(self, local, chunks):
         import torch.distributed as dist
-        if self.rank == 0:
-            chunks = list(self.gathered[k].chunk(self.world))
-            work = dist.gather(self.local[k], gather_list=chunks, dst=0, async_op=True)
-            work.wait()  # orders the current stream after the gather; does not block the host
-            self.ctx.deinterleave_device(self.gathered[k].data_ptr(), self.world, self.rpr, self.width, self.height,
-                                         self.frames[k].data_ptr(), stream.cuda_stream)
-            return self.frames[k], None
-        work = dist.gather(self.local[k], dst=0, async_op=True)
-        self.pending[k] = work
-        return None, work
+        return dist.gather(local, gather_list=chunks, dst=0, async_op=True)
 
     def finish(self):
         """Orders everything issued so far before the caller's current stream."""
-        with self.torch.cuda.stream(self.stream):
+        with self.torch.cuda.stream(self.comm):
             for i, w in enumerate(self.pending):
                 if w is not None:
                     w.wait()
                     self.pending[i] = None
-        self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = self.torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.stream)
+        cur.wait_stream(self.comm)
 
 
 def assemble_rows(blocks, height):
