@@ -70,9 +70,63 @@ def hip_event_api():
     return lib
 
 
-def cpu_baseline(textures, cam_of):
-    """The oracle (CPU restatement of the reference, bit-equal to it) on one whole frame of the same
-    workload with all the host threads OpenMP gives it (about 15 s on 8 cores, 2 s on the GPU box)."""
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return min(cores, omp) if omp else cores
+
+
+def reference_baseline(gpu_frame):
+    """The reference's own code (oracle/_ref/libref.so: its unmodified sources compiled where they lie,
+    plus our extern "C" harness around Scene::traceRay) on one whole frame of the same workload.
+    Returns None when that library has not been built or cannot run here."""
+    import tempfile
+    import numpy as np
+    import oracle
+    if not os.path.exists(oracle.REF_LIB_PATH):
+        return None
+    try:
+        lib = ctypes.CDLL(oracle.REF_LIB_PATH)
+        lib.ref_scene_create.restype = ctypes.c_void_p
+        lib.ref_scene_create.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_char_p, ctypes.c_char_p]
+        lib.ref_render.restype = ctypes.c_double
+        lib.ref_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        # the reference opens "../resources/bunny.obj" relative to its working directory
+        # (and "../resources/map2.jpg", its default environment map, a copy of envmap.jpg)
+        base = tempfile.mkdtemp(prefix="rtx_ref_")
+        os.mkdir(os.path.join(base, "run"))
+        os.mkdir(os.path.join(base, "resources"))
+        for name, src in (("bunny.obj", "bunny.obj"), ("water.jpg", "water.jpg"), ("envmap.jpg", "envmap.jpg"),
+                          ("map2.jpg", "envmap.jpg"), ("map.jpg", "map.jpg")):
+            os.symlink(os.path.join(ROOT, "assets", src), os.path.join(base, "resources", name))
+        # the reference prints to stdout; this program's stdout carries exactly one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            h = lib.ref_scene_create(os.path.join(base, "run").encode(), 31, os.path.join(base, "resources", "envmap.jpg").encode(),
+                                     os.path.join(base, "resources", "water.jpg").encode())
+            if not h:
+                return None
+            cores = host_cores()
+            frame = np.zeros((HEIGHT, WIDTH, 3), np.uint8)
+            dt = lib.ref_render(ctypes.c_void_p(h), WIDTH, HEIGHT, DEPTH, cores, frame.ctypes.data)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+    except Exception as e:  # missing library dependencies, a different host ...
+        print("reference baseline unavailable: %r" % (e,), file=sys.stderr)
+        return None
+    return {"seconds": dt, "cores": cores, "same_bytes_as_gpu_frame": bool(gpu_frame is not None and np.array_equal(frame, gpu_frame))}
+
+
+def cpu_baseline(textures, cam_of, gpu_frame=None):
+    """One whole frame of the same workload on the host cores: the reference's own code when
+    oracle/_ref/libref.so is there (kind "reference"), else the oracle (CPU restatement of the reference,
+    bit-equal to it; kind "port").  Ray counts come from the oracle's statistics either way."""
     import oracle
     from raytracing_amd.rtx import OPT_STATS, Backend
     cpu = Backend(oracle.ORACLE_LIB_PATH)
@@ -85,13 +139,18 @@ def cpu_baseline(textures, cam_of):
     _, st = ctx.render(cam_of(cpu), WIDTH, HEIGHT, DEPTH, row_first=0, row_step=step, want_stats=True)
     dt = time.time() - t0
     rays = st.rays
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
-    if omp:
-        cores = min(cores, omp)
+    cores = host_cores()
+    ref = reference_baseline(gpu_frame)
+    if ref is not None:
+        return {
+            "value": round(rays / ref["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": ref["cores"], "kind": "reference",
+            "sample": "one whole frame of the same workload (3840x2160, depth 4) by the reference's own Scene::traceRay "
+                      "(oracle/_ref/libref.so), OpenMP dynamic rows as in Scene::render: %d sceneIntersect calls (it also traces "
+                      "the zero-weight children and the shadow rays the GPU prunes) in %.2f s; the bit-equal port took %.2f s"
+                      % (rays, ref["seconds"], dt),
+            "ms_per_frame": round(ref["seconds"] * 1e3, 1),
+            "same_bytes_as_gpu_frame": ref["same_bytes_as_gpu_frame"],
+        }
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": "one whole frame of the same workload (3840x2160, depth 4), OpenMP dynamic rows like the reference: "
@@ -250,7 +309,11 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(textures, lambda b: b.default_camera())
+            gpu_frame = renderer.render(cam)[0]
+            renderer.finish()
+            torch.cuda.synchronize()
+            out["cpu_baseline"] = cpu_baseline(textures, lambda b: b.default_camera(),
+                                               gpu_frame.cpu().numpy().reshape(HEIGHT, WIDTH, 3))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
