@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, DEPTH = 3840, 2160, 4
 
 # Algorithmic FP32 operation counts per unit of work (mul, add, sub, compare-free; div, sqrt, rcp
-# count 1 each): the per-unit figures of the hot-path scope table, restated in DESIGN.md.
+# count 1 each), per unit of work as the kernels do it.
 FLOPS = {
     "primary_ray": 28,        # ray generation + normalize
     "sphere_test": 19,

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
         if (quad) tracePaths<STATS>(s, q, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         else tracePaths<STATS>(s, q, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
-        if (lane == 0 && !quad) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile);
+        // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)
+        if (lane == 0 && (!quad || sub == 0u)) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -391,7 +392,7 @@ struct rtx_ctx {
     unsigned *d_entries = nullptr;     // d_order_by_cost with the longest tiles split into quarters; [cap] = entry count
     void *d_sort_tmp = nullptr;
     size_t sched_cap = 0, sort_tmp_bytes = 0;
-    std::vector<unsigned char> cost_key, by_cost_key;  // the (camera, frame) those two belong to
+    std::vector<unsigned char> cost_key, by_cost_key;  // the (camera, frame) the costs / the sorted list belong to
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -597,8 +598,9 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
     // Longest tiles first.  The first frame of a view goes by classes from projected bounding boxes
     // (tileOrder); every frame records what each tile cost, and the second frame of the same view
-    // sorts the tiles by that, on the device and in stream order (one radix sort, about as long as
-    // 3 % of a 4K frame), after which the list is kept until the view changes.
+    // sorts the tiles by that, on the device and in stream order, after which the list is kept until
+    // the view changes.  (The sort and the list expansion take 0.05-0.15 ms, more than they gain on a
+    // single frame: a camera that moves every frame stays on the static order.)
     bool sort_now = false;
     const unsigned *n_entries_dev = nullptr;
     unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;

@@ -151,6 +151,21 @@ def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_fra
     assert counts[0] == (st.primary_rays, st.secondary_rays, st.shadow_rays, st.sky_lookups, st.lit_lights)
 
 
+def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures):
+    """A camera that moves from frame to frame (every frame is the first of its view), then stands
+    still for two frames (cost-sorted order, quad mode): all frames equal the oracle's."""
+    ctx = make_default_context(hip, textures, sky="map.jpg")
+    octx = make_default_context(oracle_backend, textures, sky="map.jpg")
+    cam = hip.default_camera()
+    for step in (0, 1, 2, 3, 3, 3):
+        cam.origin[0] = -7.5 + 0.4 * step
+        cam.origin[2] = -5.0 - 0.3 * step
+        a = ctx.render(cam, 320, 240, 4)
+        ocam = oracle_backend.default_camera()
+        ocam.origin[0], ocam.origin[2] = cam.origin[0], cam.origin[2]
+        assert np.array_equal(a, octx.render(ocam, 320, 240, 4))
+
+
 def test_deterministic(hip, textures):
     cam = hip.default_camera()
     ctx = make_default_context(hip, textures, sky="map.jpg")
