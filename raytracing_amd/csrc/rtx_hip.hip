@@ -628,8 +628,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
     if (sort_now) {
-        // by cost in units of 2^11 ticks (20 us); the sort is stable, so the many cheap tiles keep their
-        // raster order and with it the locality of their texture fetches
+        // by exact cost: with coarser keys the queues end up less evenly loaded
         HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(c->d_sort_tmp, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
                                                                  c->d_order_by_cost, (int)n_tiles, 0, 32, stream));
         // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.1 ms,

@@ -152,12 +152,13 @@ def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_fra
 
 
 def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures):
-    """A camera that moves from frame to frame (every frame is the first of its view), then stands
-    still for two frames (cost-sorted order, quad mode): all frames equal the oracle's."""
+    """A camera that stands still, moves, stands still, moves on: frames are scheduled by the static
+    classes, by their own view's costs, or by another view's list (renewed every few frames).  None of
+    that may show in the pixels."""
     ctx = make_default_context(hip, textures, sky="map.jpg")
     octx = make_default_context(oracle_backend, textures, sky="map.jpg")
     cam = hip.default_camera()
-    for step in (0, 1, 2, 3, 3, 3):
+    for step in (0, 0, 1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
         cam.origin[0] = -7.5 + 0.4 * step
         cam.origin[2] = -5.0 - 0.3 * step
         a = ctx.render(cam, 320, 240, 4)
