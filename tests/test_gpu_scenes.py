@@ -309,6 +309,22 @@ def test_full_size_properties_4k(hip, oracle_backend, textures):
     assert np.array_equal(whole[5::16], sample)
 
 
+def test_full_size_properties_8k(hip, oracle_backend, textures):
+    """7680x4320, depth 4, full scene (the largest frame BASELINE.json names): run-to-run equality across
+    the three scheduling regimes (static order, cost-sorted order, kept list), the 8-way row-interleaved
+    shares reassemble to the same bytes, and a 1/64 row sample equals the oracle's rows."""
+    cam = hip.default_camera()
+    ctx = make_default_context(hip, textures)
+    W, H, D = 7680, 4320, 4
+    whole = ctx.render(cam, W, H, D)
+    assert np.array_equal(whole, ctx.render(cam, W, H, D))
+    assert np.array_equal(whole, ctx.render(cam, W, H, D))
+    blocks = [ctx.render(cam, W, H, D, row_first=r, row_step=8) for r in range(8)]
+    assert np.array_equal(assemble_rows(blocks, H), whole)
+    sample = make_default_context(oracle_backend, textures).render(cam, W, H, D, row_first=37, row_step=64)
+    assert np.array_equal(whole[37::64], sample)
+
+
 def test_host_layer_decodes_files_on_the_product_library(hip, textures):
     """rt_scene_load_default (JPEG decode + model parse inside the product library) gives the same
     frame as handing over pre-decoded textures."""
