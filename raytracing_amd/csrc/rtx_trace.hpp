@@ -123,8 +123,8 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                 }
             }
         }
-        if (cur == kDone) break;
-        {
+        // the lanes that hold a leaf test it, and go on testing while what they pop is a leaf again
+        while (cur != kDone && cur < 0) {
             const int ti = ~cur;
             const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
             const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
@@ -179,10 +179,13 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                     if (t < t_exit) return true;
                 }
             }
+            cur = kDone;
+            if (sp > 0) {
+                --sp;
+                cur = stack[sp * stride];
+            }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = stack[sp * stride];
+        if (cur == kDone) break;
     }
     return false;
 }
