@@ -550,7 +550,9 @@ void buildGrid(rtx_ctx &s, V3 lo, V3 hi) {
             int i = int(fx), j = int(fy), k = int(fz);
             if (i < 0 || j < 0 || k < 0 || i >= size || j >= size || k >= size) continue;  // reference: UB
             std::vector<int> &cell = g->tris[i][j][k];
-            if (std::find(cell.begin(), cell.end(), (int)ti) == cell.end()) cell.push_back((int)ti);
+            // the reference looks the whole list through for ti; ti can only be its last element (a
+            // triangle's three vertices are entered one after the other)
+            if (cell.empty() || cell.back() != (int)ti) cell.push_back((int)ti);
         }
     }
     s.grid = g;
