@@ -69,7 +69,10 @@ typedef struct rtx_frame {
 
 /* Ray counts of the last render ("ray" = one sceneIntersect call, src/Scene.cpp:29).  Only filled
  * when the context was rendered with statistics enabled (rtx_set_option RTX_OPT_STATS = 1), which
- * costs one atomic per wavefront per counter. */
+ * costs one atomic per wavefront per counter.  The ray counts, sky_lookups and lit_lights are per
+ * pixel whatever the schedule; in quad mode (RTX_OPT_QUAD, second and later frames of a view) the
+ * per-test counters below them also count the tests of the three lanes that repeat a pixel's
+ * closest-hit ray. */
 typedef struct rtx_stats {
     uint64_t primary_rays;    /* traceRay calls at full depth                                  */
     uint64_t secondary_rays;  /* traceRay calls below it that reach sceneIntersect             */
