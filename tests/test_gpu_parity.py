@@ -79,6 +79,35 @@ def test_depth_zero_is_sky_only(hip, oracle_backend, textures):
     assert np.array_equal(a, b)  # the sky lookup alone: atan2f / acosf -> texel
 
 
+@pytest.mark.parametrize("sky", ["envmap.jpg", "map.jpg"])
+def test_sky_texels_for_two_million_directions(hip, oracle_backend, textures, sky):
+    """Sky::getColorAt alone (traceRay at depth 0) on random directions, on directions along and next to
+    the axes and the poles, and on directions placed on texel borders: the HIP path's restatements of
+    atan2f / acosf must pick the texel the C library's functions pick, every time."""
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hgt, wid = textures[sky].shape[:2]
+    k = 200_000  # on texel borders: angle = border angle, nudged by a few float ulps either way
+    col = rng.integers(0, wid, k)
+    row = rng.integers(1, hgt, k)
+    theta = (col / wid - 0.5) * 2 * np.pi
+    phi = row / hgt * np.pi
+    on_col = np.stack([np.cos(theta) * np.sin(phi), np.cos(phi), np.sin(theta) * np.sin(phi)], 1)
+    d[:k] = on_col
+    d = d.astype(np.float32)
+    d[k:2 * k] = np.nextafter(d[:k], np.float32(2.0))
+    d[2 * k:3 * k] = np.nextafter(d[:k], np.float32(-2.0))
+    special = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [-1, 0, -0.0], [-1, 0, 1e-30],
+                        [-1, 0, -1e-30], [1e-30, 1, 0], [0, 0.99999994, 0.00034526698], [0.6, 0.8, 0], [-0.6, -0.8, 0]], np.float32)
+    d[3 * k:3 * k + len(special)] = special
+    o = np.zeros_like(d)
+    got = make_default_context(hip, textures, mask=0, sky=sky).trace_rays(o, d, 0)
+    want = make_default_context(oracle_backend, textures, mask=0, sky=sky).trace_rays(o, d, 0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_intersections_bit_exact(hip, oracle_backend, textures, kats):
     """Scene::sceneIntersect on 40 000 rays: hit flag, point, normal, material -- bit for bit."""
     got = make_default_context(hip, textures, sky="map.jpg").intersect_rays(kats["orig"], kats["dir"])

@@ -97,7 +97,6 @@ def test_both_tree_builders_give_the_same_hits(hip, textures, n_tris):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("builder", [1, 2])
 def _subdivide(verts, idx, levels):
     """Each triangle into four (edge midpoints), `levels` times; midpoints are not shared (a soup)."""
     tri = verts[idx].astype(np.float32)  # (n, 3, 3)
@@ -137,6 +136,7 @@ def test_million_triangle_mesh_equals_oracle(hip, oracle_backend, textures):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("builder", [1, 2])
 def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures, builder):
     """All triangles share one centroid (identical Morton codes, no usable split plane): the tree
     must still be valid."""
