@@ -64,6 +64,11 @@ RTX_DEV float refPowf(const RefMathTables &T, float x, float y) {
     return (float)(yy * s);
 }
 
+// The three routines below follow fdlibm's case analysis, but a wave executes every case some lane
+// takes, so whatever the cases have in common -- the rational approximation and its division in
+// acosf, the division of the argument reduction in atanf -- is written once, on operands selected
+// per case.  Each case still performs exactly the operations fdlibm performs, in its order.
+
 // fdlibm e_acosf
 RTX_DEV float refAcosf(float x) {
     const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
@@ -73,74 +78,50 @@ RTX_DEV float refAcosf(float x) {
     const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
     if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
     if (ix > 0x3f800000) return __uint_as_float(0x7fc00000u);  // |x| > 1: NaN
-    if (ix < 0x3f000000) {                                     // |x| < 0.5
-        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
-        const float z = x * x;
-        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const float r = p / q;
-        return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    if (hx < 0) {  // x < -0.5
-        const float z = (1.0f + x) * 0.5f;
-        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const float s = sqrtf(z);
-        const float r = p / q;
-        const float w = r * s - pio2_lo;
-        return pi - 2.0f * (s + w);
-    }
-    const float z = (1.0f - x) * 0.5f;  // x > 0.5
-    const float s = sqrtf(z);
-    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
-    const float c = (z - df * df) / (s + df);
+    const bool small = ix < 0x3f000000;                        // |x| < 0.5
+    if (small && ix <= 0x23000000) return pio2_hi + pio2_lo;
+    // z = x*x, (1+x)/2 or (1-x)/2; for x < -0.5, 1 + x is the same operation as 1 - |x|
+    const float z = small ? x * x : (1.0f - fabsf(x)) * 0.5f;
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
     const float r = p / q;
+    if (small) return pio2_hi - (x - (pio2_lo - x * r));
+    const float s = sqrtf(z);
+    if (hx < 0) {  // x < -0.5
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);  // x > 0.5
+    const float c = (z - df * df) / (s + df);
     const float w = r * s + c;
     return 2.0f * (df + w);
 }
 
 // fdlibm s_atanf
 RTX_DEV float refAtanf(float x) {
-    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
-    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
     const float aT[11] = {3.3333334327e-01f,  -2.0000000298e-01f, 1.4285714924e-01f,  -1.1111110449e-01f,
                           9.0908870101e-02f,  -7.6918758452e-02f, 6.6610731184e-02f,  -5.8335702866e-02f,
                           4.9768779427e-02f,  -3.6531571299e-02f, 1.6285819933e-02f};
     const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
     if (ix >= 0x50800000) {  // |x| >= 2^34
         if (ix > 0x7f800000) return x + x;
-        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+        return hx > 0 ? 1.5707962513e+00f + 7.5497894159e-08f : -1.5707962513e+00f - 7.5497894159e-08f;
     }
-    int id;
-    float hi = 0.0f, lo = 0.0f;
-    if (ix < 0x3ee00000) {  // |x| < 0.4375
-        if (ix < 0x31000000) return x;
-        id = -1;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) {
-                id = 0, hi = atanhi[0], lo = atanlo[0];
-                x = (2.0f * x - 1.0f) / (2.0f + x);
-            } else {
-                id = 1, hi = atanhi[1], lo = atanlo[1];
-                x = (x - 1.0f) / (x + 1.0f);
-            }
-        } else if (ix < 0x401c0000) {
-            id = 2, hi = atanhi[2], lo = atanlo[2];
-            x = (x - 1.5f) / (1.0f + 1.5f * x);
-        } else {
-            id = 3, hi = atanhi[3], lo = atanlo[3];
-            x = -1.0f / x;
-        }
-    }
-    const float z = x * x, w = z * z;
+    const bool small = ix < 0x3ee00000;  // |x| < 0.4375: no reduction
+    if (small && ix < 0x31000000) return x;
+    // reduced argument num / den: (2x-1)/(2+x), (x-1)/(x+1), (x-1.5)/(1+1.5x), -1/x
+    const float ax = fabsf(x);
+    float num, den, hi, lo;
+    if (ix < 0x3f300000) num = 2.0f * ax - 1.0f, den = 2.0f + ax, hi = 4.6364760399e-01f, lo = 5.0121582440e-09f;
+    else if (ix < 0x3f980000) num = ax - 1.0f, den = ax + 1.0f, hi = 7.8539812565e-01f, lo = 3.7748947079e-08f;
+    else if (ix < 0x401c0000) num = ax - 1.5f, den = 1.0f + 1.5f * ax, hi = 9.8279368877e-01f, lo = 3.4473217170e-08f;
+    else num = -1.0f, den = ax, hi = 1.5707962513e+00f, lo = 7.5497894159e-08f;
+    const float t = small ? x : num / den;
+    const float z = t * t, w = z * z;
     const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
     const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
-    if (id < 0) return x - x * (s1 + s2);
-    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    if (small) return t - t * (s1 + s2);
+    const float r = hi - ((t * (s1 + s2) - lo) - t);
     return hx < 0 ? -r : r;
 }
 
@@ -150,18 +131,18 @@ RTX_DEV float refAtan2f(float y, float x) {
     const int hx = (int)__float_as_uint(x), hy = (int)__float_as_uint(y);
     const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-    if (hx == 0x3f800000) return refAtanf(y);
+    const bool unit = hx == 0x3f800000;  // x == 1: atanf(y)
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
-    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
-    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (!unit) {
+        if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+        if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    }
     const int k = (iy - ix) >> 23;
-    float z;
-    if (k > 60)
-        z = pi_o_2 + 0.5f * pi_lo;
-    else if (hx < 0 && k < -60)
-        z = 0.0f;
-    else
-        z = refAtanf(fabsf(y / x));
+    const float t = refAtanf(unit ? y : fabsf(y / x));  // the one evaluation both cases share
+    if (unit) return t;
+    float z = t;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
     switch (m) {
         case 0: return z;
         case 1: return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
