@@ -220,6 +220,27 @@ def test_light_pruning_is_exact_for_any_intensities(hip, oracle_backend, texture
     assert np.array_equal(frames[2], frames[1])
 
 
+@pytest.mark.parametrize("n_lights", [0, 1, 4, 5, 8])
+def test_any_number_of_lights_in_both_modes(hip, oracle_backend, textures, n_lights):
+    """0 to 8 lights (the LDS staging's limit): the one-light-per-trip loop of the normal mode and the
+    four-lights-per-batch loop of quad mode (second batch, partial batches) against the oracle."""
+    from raytracing_amd.rtx import OPT_QUAD
+    rng = np.random.default_rng(n_lights)
+    lights = np.concatenate([rng.uniform(-40, 40, size=(n_lights, 3)) + np.array([0, 45.0, 0]),
+                             rng.uniform(0.3, 1.2, size=(n_lights, 1))], axis=1).astype(np.float32)
+    cam = hip.default_camera()
+    frames = []
+    for b, opts in ((oracle_backend, []), (hip, [(OPT_QUAD, 0)]), (hip, [(OPT_QUAD, 2)])):
+        ctx = make_default_context(b, textures, sky="map.jpg", options=opts, commit=False)
+        ctx.set_lights(lights)
+        ctx.commit()
+        for _ in range(1 if b is oracle_backend else 3):  # the third frame of a view runs from the cost-sorted list
+            frame = ctx.render(cam, 256, 192, 3)
+        frames.append(frame)
+    assert np.array_equal(frames[1], frames[0])
+    assert np.array_equal(frames[2], frames[0])
+
+
 def test_api_errors(hip, textures):
     ctx = hip.create()
     with pytest.raises(RtxError) as e:
