@@ -241,6 +241,75 @@ def test_any_number_of_lights_in_both_modes(hip, oracle_backend, textures, n_lig
     assert np.array_equal(frames[2], frames[0])
 
 
+def _random_scene(ctx, backend, textures, seed):
+    """Random analytic primitives with random materials around the default camera's view, plus water,
+    islands and a small random triangle mesh."""
+    rng = np.random.default_rng(seed)
+    n_mat = int(rng.integers(3, 12))
+    mats = np.zeros((n_mat, 9), np.float32)
+    mats[:, 0] = rng.uniform(1.0, 1.8, n_mat)                       # refractive index
+    mats[:, 1:5] = rng.uniform(0, 1, (n_mat, 4)) * (rng.uniform(size=(n_mat, 4)) > 0.35)  # albedo, some exactly 0
+    mats[:, 5:8] = rng.uniform(0, 1, (n_mat, 3))                    # diffuse colour
+    mats[:, 8] = rng.choice([5.0, 10.0, 50.0, 125.0, 1425.0], n_mat)  # specular exponent
+    ctx.set_materials(mats)
+    nl = int(rng.integers(1, 6))
+    ctx.set_lights(np.concatenate([rng.uniform(-30, 30, (nl, 3)) + [0, 40, 0], rng.uniform(0.4, 1.5, (nl, 1))], 1))
+    centre = np.array([0.0, -1.0, -22.0])
+    ns = int(rng.integers(0, 9))
+    if ns:
+        ctx.set_spheres(centre + rng.uniform(-9, 9, (ns, 3)), rng.uniform(0.5, 3.0, ns), rng.integers(0, n_mat, ns))
+    nb = int(rng.integers(0, 7))
+    if nb:
+        a = centre + rng.uniform(-10, 10, (nb, 3))
+        ctx.set_boxes(a, a + rng.uniform(0.5, 4.0, (nb, 3)) * rng.choice([-1.0, 1.0], (nb, 3)), rng.integers(0, n_mat, nb))
+    nt = int(rng.integers(0, 7))
+    if nt:
+        c = centre + rng.uniform(-10, 10, (nt, 1, 3))
+        ctx.set_triangles((c + rng.normal(scale=3.0, size=(nt, 3, 3))).reshape(nt, 9), rng.integers(0, n_mat, nt))
+    ni = int(rng.integers(0, 6))
+    if ni:
+        isl = np.concatenate([rng.uniform(-25, 25, (ni, 1)), rng.uniform(-45, -10, (ni, 1)), rng.uniform(2, 9, (ni, 2))], 1)
+        ctx.set_islands(isl, -4.0, int(rng.integers(0, n_mat)), rng.uniform(0, 1, 3), rng.uniform(0, 1, 3))
+    if rng.uniform() < 0.8:
+        ctx.set_water(textures["water"], -4.5, float(rng.choice([10.0, 3.5])), int(rng.integers(0, n_mat)))
+    if rng.uniform() < 0.7:
+        verts, idx = _soup(int(rng.integers(1, 400)), seed + 1000, spread=5.0, size=1.2)
+        ctx.set_mesh(verts + np.float32([0, 1, 8]), idx, int(rng.integers(0, n_mat)))
+    ctx.set_envmap(textures["map.jpg"], int(rng.integers(0, 300)))
+    ctx.commit()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_equal_the_oracle(hip, oracle_backend, textures, seed):
+    """Ten random scenes (materials with zero and non-zero weights, 1-5 lights, spheres, boxes, loose
+    triangles, islands, water, a triangle-soup mesh; reflection and refraction to depth 5), each frame
+    rendered three times on the GPU (static order, cost-sorted order, kept list): all equal the oracle's."""
+    frames = []
+    for b in (oracle_backend, hip):
+        ctx = b.create()
+        _random_scene(ctx, b, textures, seed)
+        cam = b.default_camera()
+        for _ in range(1 if b is oracle_backend else 3):
+            frames.append(ctx.render(cam, 192, 144, 5))
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+
+
+def test_commit_rejects_lists_beyond_the_lds_staging(hip, textures):
+    for what in ("spheres", "lights", "materials"):
+        ctx = hip.create()
+        mats = np.tile(hip.default_materials()[:1], (33 if what == "materials" else 4, 1))
+        ctx.set_materials(mats)
+        if what == "spheres":
+            ctx.set_spheres(np.zeros((17, 3)), np.ones(17), np.zeros(17, np.int32))
+        if what == "lights":
+            ctx.set_lights(np.ones((9, 4)))
+        ctx.set_envmap(textures["map.jpg"])
+        with pytest.raises(RtxError) as e:
+            ctx.commit()
+        assert e.value.code == -5
+
+
 def test_api_errors(hip, textures):
     ctx = hip.create()
     with pytest.raises(RtxError) as e:
