@@ -117,6 +117,12 @@ enum rtx_option {
                                  the previous frame of the view are traced with four lanes per pixel
                                  (the shadow rays of a node go out side by side): 0 never, 1 the tiles
                                  that would hold the frame up, 2 every tile.  Pixels do not change   */
+    RTX_OPT_SPP = 9,          /* 1 (default) or 4: samples per pixel.  No counterpart in the reference
+                                 (one ray through the pixel centre, src/Scene.cpp:217-218).  With 4,
+                                 sample k goes through (col + 0.5 + dx[k], row + 0.5 + dy[k]) with
+                                 dx = {.125, -.375, .375, -.125}, dy = {.375, .125, -.125, -.375} (a
+                                 rotated grid); the pixel is (((c0 + c1) + c2) + c3) * 0.25 in
+                                 binary32, then clamped and truncated to bytes as with one sample   */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:
@@ -138,7 +144,11 @@ int rtx_set_materials(rtx_ctx *ctx, const float *m9, int n);
  * lights are applied in array order (src/Scene.cpp:64). */
 int rtx_set_lights(rtx_ctx *ctx, const float *xyzi, int n);
 /* replaces: Scene::loadSpheres + SceneObjects::spheresIntersect (src/Scene.cpp:108-115,
- * src/SceneObjects.cpp:15-26, 289-302) */
+ * src/SceneObjects.cpp:15-26, 289-302).  Of two spheres hit at the same distance the one that comes
+ * first in the arrays wins (the reference's loop keeps the first, `curDist < spheresDist`).  Up to
+ * 16 spheres are tested one after the other, as the reference does; beyond that the HIP backend
+ * walks a bounding volume hierarchy over them (same hits, same winner; rtx_stats.sphere_tests then
+ * counts the tests the walk performs, not spheres x rays). */
 int rtx_set_spheres(rtx_ctx *ctx, const float *cx, const float *cy, const float *cz, const float *r,
                     const int *mat, int n);
 /* replaces: Scene::loadCubes + cubesIntersect (src/Scene.cpp:117-131, src/SceneObjects.cpp:75-174,

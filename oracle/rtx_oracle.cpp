@@ -262,6 +262,7 @@ struct rtx_ctx {
     bool prune = false;  // the oracle follows the reference and traces zero-weight children
     float far_clip = 700.0f;
     bool mesh_grid = true;
+    int spp = 1;  // RTX_OPT_SPP
     float fprec = 0.001f;
     Stats stats;
     double last_ms = 0;
@@ -591,6 +592,10 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_BVH_BUILDER: break;  // no tree here
         case RTX_OPT_SCHEDULE_FEEDBACK: break;  // no tile schedule here
         case RTX_OPT_QUAD: break;
+        case RTX_OPT_SPP:
+            if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
+            c->spp = (int)value;
+            break;
         default: return fail(RTX_E_INVALID, "unknown option");
     }
     return RTX_OK;
@@ -746,10 +751,11 @@ static int checkFrame(const rtx_ctx *c, const rtx_camera *cam, const rtx_frame *
 }
 
 // primary ray direction of pixel (row i, column j), src/Scene.cpp:217-220
-static inline V3 primaryDir(const rtx_camera *cam, int width, int height, size_t i, size_t j) {
+// (dx, dy: offset of the sample from the pixel centre, 0 for the reference's one sample per pixel)
+static inline V3 primaryDir(const rtx_camera *cam, int width, int height, size_t i, size_t j, float dx = 0.0f, float dy = 0.0f) {
     const float *M = cam->basis;
-    float x = (j + 0.5f) - width / 2.0f;
-    float y = -(i + 0.5f) + height / 2.0f;
+    float x = ((j + 0.5f) + dx) - width / 2.0f;
+    float y = -((i + 0.5f) + dy) + height / 2.0f;
     float z = -height / (2.0f * cam->tan_half_fov);
     // mat3 * vec3, include/glm/detail/type_mat3x3.inl:468-474
     V3 d = v3(M[0] * x + M[3] * y + M[6] * z, M[1] * x + M[4] * y + M[7] * z, M[2] * x + M[5] * y + M[8] * z);
@@ -782,13 +788,24 @@ int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned c
     {
         Stats local;
         Stats *st = c->count ? &local : nullptr;
-#pragma omp for schedule(dynamic)
+        // (pixels are independent: rows and columns are dealt out together, so that a frame of a few
+        // long rows still uses every thread)
+#pragma omp for collapse(2) schedule(dynamic, 64)
         for (int k = 0; k < rows; ++k) {
-            const size_t i = (size_t)f->row_first + (size_t)k * f->row_step;
-            unsigned char *row = bgr_out + (size_t)k * width * 3;
             for (size_t j = 0; j < (size_t)width; ++j) {
-                V3 dir = primaryDir(cam, width, height, i, j);
-                V3 col = traceRay(*c, camera, dir, f->depth, f->depth, st);
+                const size_t i = (size_t)f->row_first + (size_t)k * f->row_step;
+                unsigned char *row = bgr_out + (size_t)k * width * 3;
+                V3 col;
+                if (c->spp == 1) {
+                    V3 dir = primaryDir(cam, width, height, i, j);
+                    col = traceRay(*c, camera, dir, f->depth, f->depth, st);
+                } else {  // RTX_OPT_SPP = 4: rotated grid, summed in sample order, times 0.25
+                    static const float dx[4] = {0.125f, -0.375f, 0.375f, -0.125f}, dy[4] = {0.375f, 0.125f, -0.125f, -0.375f};
+                    col = traceRay(*c, camera, primaryDir(cam, width, height, i, j, dx[0], dy[0]), f->depth, f->depth, st);
+                    for (int k = 1; k < 4; ++k)
+                        col = col + traceRay(*c, camera, primaryDir(cam, width, height, i, j, dx[k], dy[k]), f->depth, f->depth, st);
+                    col = col * 0.25f;
+                }
                 unsigned char red = (unsigned char)(255 * std::max(0.0f, std::min(1.0f, col.x)));
                 unsigned char green = (unsigned char)(255 * std::max(0.0f, std::min(1.0f, col.y)));
                 unsigned char blue = (unsigned char)(255 * std::max(0.0f, std::min(1.0f, col.z)));

@@ -73,6 +73,13 @@ struct DevScene {
     const float4 *spheres;
     const int *sphere_mat;
     int n_spheres;
+    // More spheres than the LDS staging holds (kMaxSmallPrims): a BVH2 over their boxes (leaf ~child =
+    // sphere index), null otherwise.  The boxes are the geometric ones; the slack that the rounding
+    // of Sphere::rayIntersect needs is added per ray (sphereWalk in rtx_trace.hpp).
+    const BvhNode *sphere_bvh;
+    float sphere_root_c[3];  // centre of the box around all spheres
+    float sphere_root_h;     // its half diagonal
+    float sphere_rmax;       // largest radius
     // loose triangles: v0, v1, v2 (9 floats each)
     const float *tris;
     const int *tri_mat;
@@ -144,8 +151,10 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
     };
     copy(q.materials, s.materials, s.n_materials * 9);
     copy(q.lights, s.lights, s.n_lights * 4);
-    copy(q.spheres, s.spheres, s.n_spheres * 4);
-    copy(q.sphere_mat, s.sphere_mat, s.n_spheres);
+    if (s.n_spheres <= kMaxSmallPrims) {  // larger sets stay in global memory behind their BVH
+        copy(q.spheres, s.spheres, s.n_spheres * 4);
+        copy(q.sphere_mat, s.sphere_mat, s.n_spheres);
+    }
     copy(q.islands, s.islands, s.n_islands * 4);
     copy(q.tris, s.tris, s.n_tris * 9);
     copy(q.tri_mat, s.tri_mat, s.n_tris);

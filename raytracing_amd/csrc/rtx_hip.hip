@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kBlock = 256;     // 4 waves per block
 constexpr int kStackDepth = 32; // LDS traversal stack entries per lane (checked against the tree's depth)
+constexpr int kMaxSpheres = 1 << 24;
 
 struct DevCamera {
     float ox, oy, oz;
@@ -34,12 +35,13 @@ struct DevCamera {
 
 struct DevFrame {
     int width, height, depth, row_first, row_step, rows;
+    int spp;  // RTX_OPT_SPP: 1 or 4
 };
 
-// src/Scene.cpp:217-220
-RTX_DEV V3 primaryDir(const DevCamera &cam, int width, int height, int i, int j) {
-    float x = ((float)j + 0.5f) - (float)width / 2.0f;
-    float y = -((float)i + 0.5f) + (float)height / 2.0f;
+// src/Scene.cpp:217-220; (dx, dy) = offset of the sample from the pixel centre, 0 in the reference
+RTX_DEV V3 primaryDir(const DevCamera &cam, int width, int height, int i, int j, float dx = 0.0f, float dy = 0.0f) {
+    float x = (((float)j + 0.5f) + dx) - (float)width / 2.0f;
+    float y = -(((float)i + 0.5f) + dy) + (float)height / 2.0f;
     float z = (float)(-height) / (2.0f * cam.tan_half_fov);
     // mat3 * vec3: include/glm/detail/type_mat3x3.inl:468-474
     V3 d = v3(cam.m[0] * x + cam.m[3] * y + cam.m[6] * z, cam.m[1] * x + cam.m[4] * y + cam.m[7] * z,
@@ -125,29 +127,51 @@ __global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const u
     }
 }
 
+// The pixel a lane works on; with several samples per pixel (WIDE build only) the lane traces them
+// one after the other.
+struct PixelJob {
+    int row, col;  // image row, column
+};
+
 // Advances the lane's path, one ray per trip, until it is complete; the pixel's B,G,R bytes
 // (include/bitmap_image.hpp:207-209) go to `bgr` (the wave's tile buffer in LDS).
-template <bool STATS>
-__device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool active,
-                                           const int quad_j, unsigned char *bgr, int *stack, LaneCounters<STATS> &lc) {
+template <bool STATS, bool WIDE>
+__device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, PixelJob job,
+                                           PathState &st, Frame *frames, bool active, const int quad_j, unsigned char *bgr, int *stack,
+                                           LaneCounters<STATS> &lc) {
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
+    int sample = 0;
     while (active) {
         bool hit = false;
         Hit h;
         float md = 0.0f;
         if (pathCasts(st, quad_j)) {
             pathCountRay<STATS>(st, quad_j, lc);
-            hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
+            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
         }
         V3 c;
         if (pathConsume<STATS>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
+            if constexpr (WIDE) {
+                if (fr.spp > 1) {
+                    // RTX_OPT_SPP = 4: (((c0 + c1) + c2) + c3) * 0.25 over the rotated grid of include/rtx.h
+                    sum = sample == 0 ? c : sum + c;
+                    if (++sample < 4) {
+                        const float dx = sample == 1 ? -0.375f : (sample == 2 ? 0.375f : -0.125f);
+                        const float dy = sample == 1 ? 0.125f : (sample == 2 ? -0.125f : -0.375f);
+                        pathStart(st, v3(cam.ox, cam.oy, cam.oz), primaryDir(cam, fr.width, fr.height, job.row, job.col, dx, dy), fr.depth);
+                        continue;
+                    }
+                    c = sum * 0.25f;
+                }
+            }
             if (quad_j <= 0) bgr[0] = toByte(c.z), bgr[1] = toByte(c.y), bgr[2] = toByte(c.x);
             active = false;
         }
     }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(kBlock, (STATS || WIDE) ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned *heads,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
@@ -205,20 +229,23 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
         const int x0 = (int)(tile % tiles_x) * 8 + (quad ? (int)(sub & 1u) * 4 : 0);
         const int y0 = (int)(tile / tiles_x) * 8 + (quad ? (int)(sub >> 1) * 4 : 0);
         bool active;
+        PixelJob job{0, 0};
         {
             const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
             active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
             if (active) {
                 const int row = fr.row_first + pk * fr.row_step;
-                pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
+                job.row = row, job.col = px;
+                if (WIDE && fr.spp > 1) pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px, 0.125f, 0.375f), fr.depth);
+                else pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px), fr.depth);
             }
         }
         // ---- trace its paths ----
         const long long t_tile = wall_clock64();
         // two copies of the loop, one per mode: in the common one quad_j is the constant -1 and the quad
         // logic folds away
-        if (quad) tracePaths<STATS>(s, q, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
-        else tracePaths<STATS>(s, q, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
+        if (quad) tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
+        else tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
         // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)
         if (lane == 0 && (!quad || sub == 0u)) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
@@ -249,6 +276,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     flushCounters<STATS>(lc, counters);
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *__restrict__ orig,
                                                        const float *__restrict__ dir, int n, int depth,
                                                        float *__restrict__ rgb) {
@@ -259,11 +287,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     LaneCounters<false> lc;
-    const V3 c = traceRay<false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+    const V3 c = traceRay<false, WIDE>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
                                  v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, s_stack + threadIdx.x, kBlock, lc);
     rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const float *__restrict__ orig,
                                                            const float *__restrict__ dir, int n,
                                                            float *__restrict__ out16) {
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const flo
     h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
     h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
     float md;
-    const bool ok = sceneIntersect<false>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+    const bool ok = sceneIntersect<false, WIDE>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
                                           v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md,
                                           s_stack + threadIdx.x, kBlock, lc);
     float *o = out16 + 16 * (size_t)i;
@@ -380,7 +409,9 @@ struct rtx_ctx {
     int bvh_depth = 0;
     Counters *d_counters = nullptr;
     unsigned *d_heads = nullptr;      // work-queue heads of k_render
-    int resident_blocks[2] = {0, 0};  // grid size of k_render<false> / <true>
+    int resident_blocks[4] = {0, 0, 0, 0};  // grid size of k_render<STATS, WIDE>, index STATS + 2 * WIDE
+    int spp = 1;                            // RTX_OPT_SPP
+    bool big_spheres = false;               // more spheres than the LDS staging holds: they sit behind a BVH
     // launch order of the tiles, cached for the last (camera, frame, tile size) it was built for
     unsigned *d_order = nullptr;
     size_t d_order_cap = 0;
@@ -514,7 +545,7 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
         if (projectBox(cam, f->width, f->height, d.mesh_lo, d.mesh_hi, r.r)) rects.push_back(r);
         else return RTX_OK;  // the mesh may be anywhere on screen: keep the natural order
     }
-    for (size_t i = 0; i < c->spheres.size(); ++i) {
+    for (size_t i = 0; i < c->spheres.size() && !c->big_spheres; ++i) {  // (a large set is everywhere: no classes from it)
         const Material &m = c->materials[c->sphere_mat[i]];
         if (m.a2 == 0.0f && m.a3 == 0.0f) continue;
         const float4 sp = c->spheres[i];
@@ -585,7 +616,7 @@ int scheduleBuffers(rtx_ctx *c, size_t n) {
 int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
     const int rows = rtx_frame_rows(f);
     if (rows == 0) return RTX_OK;
-    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows};
+    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows, c->spp};
     const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
     const long long n_tiles = (long long)tiles_x * tiles_y;
     if (n_tiles > (long long)kTileMask) return fail(RTX_E_LIMIT, "frame too large for one launch");
@@ -613,13 +644,18 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         return e;
     }
     // blocks that are resident at once: the kernel is a loop over tiles, more blocks would only queue
-    int &resident = c->resident_blocks[c->stats ? 1 : 0];
+    // the general build of the kernel only where it is needed: a large sphere set, several samples per pixel
+    const bool wide = c->big_spheres || c->spp > 1;
+    using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned *, unsigned *,
+                                  unsigned char *, Counters *);
+    const RenderKernel kernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
+    const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
+    int &resident = c->resident_blocks[variant];
     if (resident == 0) {
         int per_cu = 0;
         hipDeviceProp_t prop;
         HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
-        if (c->stats) HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<true>, kBlock, 0));
-        else HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<false>, kBlock, 0));
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[variant], kBlock, 0));
         resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
     }
     const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
@@ -640,12 +676,8 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         HIP_OR_FAIL(hipGetLastError());
         c->by_cost_key = key;
     }
-    if (c->stats)
-        hipLaunchKernelGGL(k_render<true>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
-    else
-        hipLaunchKernelGGL(k_render<false>, dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x,
-                           (unsigned)n_tiles, order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
+    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
+                       order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
     c->cost_key = key;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
@@ -716,6 +748,11 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD: 0 never, 1 automatic, 2 every tile");
             c->quad_mode = (int)value;
             c->by_cost_key.clear();  // the entry list is rebuilt with the next frame
+            break;
+        case RTX_OPT_SPP:
+            if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
+            c->spp = (int)value;
+            c->cost_key.clear(), c->by_cost_key.clear();  // what a tile costs changes with it
             break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
@@ -835,10 +872,11 @@ int rtx_commit(rtx_ctx *c) {
     if (c->committed) return fail(RTX_E_STATE, "already committed");
     if (c->sky_w == 0) return fail(RTX_E_STATE, "rtx_commit: no environment map (the reference cannot render without one)");
     if (c->materials.empty()) return fail(RTX_E_STATE, "rtx_commit: no materials");
-    if ((int)c->materials.size() > kMaxMaterials || (int)c->lights.size() > kMaxLights || (int)c->spheres.size() > kMaxSmallPrims ||
-        (int)c->tri_mat.size() > kMaxSmallPrims || (int)c->box_mat.size() > kMaxSmallPrims || (int)c->islands.size() > kMaxSmallPrims)
-        return fail(RTX_E_LIMIT, "rtx_commit: the analytic lists are staged in LDS: at most 32 materials, 8 lights and 16 spheres / "
-                                 "loose triangles / boxes / islands each (larger triangle sets belong in rtx_set_mesh)");
+    if ((int)c->materials.size() > kMaxMaterials || (int)c->lights.size() > kMaxLights || (int)c->tri_mat.size() > kMaxSmallPrims ||
+        (int)c->box_mat.size() > kMaxSmallPrims || (int)c->islands.size() > kMaxSmallPrims)
+        return fail(RTX_E_LIMIT, "rtx_commit: the analytic lists are staged in LDS: at most 32 materials, 8 lights and 16 loose "
+                                 "triangles / boxes / islands each (larger triangle sets belong in rtx_set_mesh; spheres have no limit)");
+    if (c->spheres.size() > (size_t)kMaxSpheres) return fail(RTX_E_LIMIT, "rtx_commit: more than 16 777 216 spheres");
     if (int e = bind(c)) return e;
     DevScene &d = c->dev;
     memset(&d, 0, sizeof d);
@@ -895,6 +933,45 @@ int rtx_commit(rtx_ctx *c) {
         for (size_t i = 0; i + 2 < c->tris.size(); i += 3) grow(d.tri_bounds, c->tris[i], c->tris[i + 1], c->tris[i + 2]);
         for (size_t i = 0; i + 2 < c->boxes.size(); i += 3) grow(d.box_bounds, c->boxes[i], c->boxes[i + 1], c->boxes[i + 2]);
         pad(d.sphere_bounds), pad(d.tri_bounds), pad(d.box_bounds);
+    }
+
+    // More spheres than the LDS staging holds: a BVH over their geometric boxes (widened by a few ulp;
+    // the slack for the rounding of the sphere test is added per ray by the walk).
+    d.sphere_bvh = nullptr;
+    c->big_spheres = (int)c->spheres.size() > kMaxSmallPrims;
+    if (c->big_spheres) {
+        std::vector<SahBox> boxes(c->spheres.size());
+        SahBox all;
+        all.reset();
+        float rmax = 0.0f;
+        for (size_t i = 0; i < c->spheres.size(); ++i) {
+            const float4 sp = c->spheres[i];
+            if (!(std::fabs(sp.x) <= 1e18f && std::fabs(sp.y) <= 1e18f && std::fabs(sp.z) <= 1e18f && std::fabs(sp.w) <= 1e18f))
+                return fail(RTX_E_INVALID, "rtx_commit: sphere coordinates must be finite (and below 1e18) when there are more than 16");
+            const float c3[3] = {sp.x, sp.y, sp.z};
+            const float r = std::fabs(sp.w);
+            rmax = std::fmax(rmax, r);
+            for (int k = 0; k < 3; ++k) {
+                const float e = 1e-6f * (std::fabs(c3[k]) + r) + 1e-30f;
+                boxes[i].lo[k] = c3[k] - r - e, boxes[i].hi[k] = c3[k] + r + e;
+            }
+            all.grow(boxes[i]);
+        }
+        std::vector<BvhNode> nodes;
+        SahBuilder builder(boxes);
+        const int depth = builder.build(nodes, kStackDepth);
+        if (depth > kStackDepth) return fail(RTX_E_LIMIT, "sphere BVH deeper than the traversal stack");
+        BvhNode *dn;
+        if (int e = upload(nodes, &dn, c->owned)) return e;
+        d.sphere_bvh = dn;
+        float h2 = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            d.sphere_root_c[k] = 0.5f * (all.lo[k] + all.hi[k]);
+            const float h = 0.5f * (all.hi[k] - all.lo[k]);
+            h2 += h * h;
+        }
+        d.sphere_root_h = std::sqrt(h2) * 1.001f;
+        d.sphere_rmax = rmax * 1.001f;
     }
 
     d.lights_plain = 1;
@@ -1071,7 +1148,8 @@ int rtx_trace_rays(rtx_ctx *c, const float *orig, const float *dir, int n, int d
     } else {
         DevScene s = c->dev;
         s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-        hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
+        if (c->big_spheres) hipLaunchKernelGGL(k_trace_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
+        else hipLaunchKernelGGL(k_trace_rays<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
             (e = hipMemcpy(rgb_out, d_c, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
             rc = failHip(e, "rtx_trace_rays");
@@ -1096,7 +1174,8 @@ int rtx_intersect_rays(rtx_ctx *c, const float *orig, const float *dir, int n, f
     } else {
         DevScene s = c->dev;
         s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-        hipLaunchKernelGGL(k_intersect_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
+        if (c->big_spheres) hipLaunchKernelGGL(k_intersect_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
+        else hipLaunchKernelGGL(k_intersect_rays<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
             (e = hipMemcpy(out16, d_c, obytes, hipMemcpyDeviceToHost)) != hipSuccess)
             rc = failHip(e, "rtx_intersect_rays");

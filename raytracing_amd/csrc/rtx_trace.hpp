@@ -191,6 +191,92 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
 }
 
 // ---------------------------------------------------------------------------------------------
+// Spheres beyond the LDS staging limit: spheresIntersect (src/SceneObjects.cpp:289-302) over a BVH2
+// of the spheres' boxes instead of the whole list.  The test at a leaf is the reference's own
+// (sphereHit); the winner is the nearest sphere and, among equal distances, the one that comes
+// first in the list, which is what the reference's loop with its strict `curDist < spheresDist`
+// keeps.
+//
+// What the walk may cull.  Sphere::rayIntersect compares dSquared = dot(L, L) - t0 * t0 with r * r,
+// where L = centre - origin; the rounding of that difference is proportional to |L|^2 (below
+// 32 * 2^-24 * |L|^2 for the operation order of sphereHit), so a ray can be accepted although it
+// passes the centre at up to r + kSphereSlack * t0, t0 being the distance of its closest approach.
+// For a far, small sphere that is well outside the sphere's box.  The boxes are therefore widened
+// per ray, by delta = kSphereSlack * (largest t0 that can still matter + largest radius): no hit can
+// matter beyond the far side of the box around all spheres, nor (once a hit is known) beyond that
+// hit's distance plus a radius.
+// ---------------------------------------------------------------------------------------------
+constexpr float kSphereSlack = 2e-3f;  // > sqrt(32 * 2^-24) = 1.38e-3
+
+// largest closest-approach distance that can matter for a ray from `orig` (no hit known yet)
+RTX_DEV float sphereReach(const DevScene &s, V3 orig) {
+    const V3 d = orig - v3(s.sphere_root_c[0], s.sphere_root_c[1], s.sphere_root_c[2]);
+    return 1.01f * (sqrtf(dot(d, d)) + s.sphere_root_h);
+}
+
+template <bool STATS>
+RTX_DEV void sphereWalk(const DevScene &s, V3 orig, V3 dir, V3 inv, float reach, float t_exit, float &minDist, int &index,
+                        int *stack, int stride, LaneCounters<STATS> &lc) {
+    const float ix = inv.x, iy = inv.y, iz = inv.z;
+    float bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));  // no candidate's closest approach lies beyond
+    float delta = kSphereSlack * (bound + s.sphere_rmax);
+    // plane distances of the widened boxes: (lo - delta - o) * inv = lo * inv + a, (hi + delta - o) * inv = hi * inv + b
+    float ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
+    float ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
+    float az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
+    int sp = 0;
+    int cur = 0;  // >= 0 inner node, < 0 sphere ~cur
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(s.sphere_bvh + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+            float tnL, tfL, tnR, tfR;
+            {
+                float t0 = __builtin_fmaf(a.x, ix, ax), t1 = __builtin_fmaf(a.w, ix, bx);
+                float t2 = __builtin_fmaf(a.y, iy, ay), t3 = __builtin_fmaf(b.x, iy, by);
+                float t4 = __builtin_fmaf(a.z, iz, az), t5 = __builtin_fmaf(b.y, iz, bz);
+                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+            }
+            {
+                float t0 = __builtin_fmaf(b.z, ix, ax), t1 = __builtin_fmaf(c.y, ix, bx);
+                float t2 = __builtin_fmaf(b.w, iy, ay), t3 = __builtin_fmaf(c.z, iy, by);
+                float t4 = __builtin_fmaf(c.x, iz, az), t5 = __builtin_fmaf(c.w, iz, bz);
+                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+            }
+            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
+            const bool both = hitL && hitR;
+            const bool leftNext = hitL && (!hitR || tnL <= tnR);
+            stack[sp * stride] = leftNext ? ch.y : ch.x;
+            sp += both ? 1 : 0;
+            cur = leftNext ? ch.x : ch.y;
+            if (hitL || hitR) continue;
+        } else {
+            const int i = ~cur;
+            const float4 sph = s.spheres[i];
+            RTX_COUNT(CNT_SPHERE_TESTS);
+            float curDist = 0.0f;
+            if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) &&
+                (curDist < minDist || (curDist == minDist && i < index))) {
+                minDist = curDist;
+                index = i;
+                if (curDist < t_exit) return;
+                bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));
+                delta = kSphereSlack * (bound + s.sphere_rmax);
+                ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
+                ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
+                az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
+            }
+        }
+        if (sp == 0) return;
+        --sp;
+        cur = stack[sp * stride];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Scene::sceneIntersect, src/Scene.cpp:29-58: categories in the reference's order, each accepting
 // only a strictly nearer hit.  It comes in three parts so that a wave can run the middle one -- the
 // mesh walk, by far the longest and the one few rays need -- for many lanes at once:
@@ -209,17 +295,34 @@ struct CastState {
     int index;
 };
 
-template <bool STATS>
-RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, float t_exit, CastState &cs, LaneCounters<STATS> &lc) {
+// WIDE = the general build of the kernels: sphere sets beyond the LDS staging limit (behind their
+// BVH), several samples per pixel.  The default build leaves both out, the code and the registers.
+template <bool STATS, bool WIDE>
+RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, float t_exit, CastState &cs, int *stack, int stride,
+                       LaneCounters<STATS> &lc) {
     float minDist = kFltMax;
     int kind = 0, index = -1;
     const V3 inv = safeInverse(dir);
     cs.minDist = minDist, cs.kind = kind, cs.index = index;
+    bool walked = false;
+    if constexpr (WIDE) {
+        if (s.sphere_bvh) {
+            // object_bounds holds the spheres' geometric boxes: the gate needs the same per-ray slack as the walk
+            const float reach = sphereReach(s, orig);
+            const float delta = kSphereSlack * (reach + s.sphere_rmax);
+            const float lo[3] = {s.object_bounds[0] - delta, s.object_bounds[1] - delta, s.object_bounds[2] - delta};
+            const float hi[3] = {s.object_bounds[3] + delta, s.object_bounds[4] + delta, s.object_bounds[5] + delta};
+            if (!slabMaybe(lo, hi, orig, inv)) return false;
+            sphereWalk<STATS>(s, orig, dir, inv, reach, t_exit, minDist, index, stack, stride, lc);
+            if (index >= 0) kind = 1;
+            walked = true;
+        }
+    }
     // one filter for everything that has a bounding box: most rays of an open scene miss it all
-    if (!slabMaybe(s.object_bounds, s.object_bounds + 3, orig, inv)) return false;
+    if (!walked && !slabMaybe(s.object_bounds, s.object_bounds + 3, orig, inv)) return false;
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
-    if (s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
+    if (!walked && s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
         for (int i = 0; i < s.n_spheres; ++i) {
             const float4 sp = q.spheres[i];
@@ -271,7 +374,7 @@ RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastStat
 }
 
 // Returns `minDist < far_clip`; minDist itself comes back in min_dist.
-template <bool STATS>
+template <bool STATS, bool WIDE>
 RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, const CastState &cs,
                      Hit &h, float &min_dist, LaneCounters<STATS> &lc) {
     float minDist = cs.minDist;
@@ -320,9 +423,10 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     h.point = orig + dir * minDist;
     int mat = 0;
     if (kind == 1) {
-        const float4 sp = q.spheres[index];
+        float4 sp;
+        if (WIDE && s.sphere_bvh) sp = s.spheres[index], mat = s.sphere_mat[index];
+        else sp = q.spheres[index], mat = q.sphere_mat[index];
         h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
-        mat = q.sphere_mat[index];
     } else if (kind == 2) {
         const float *t = q.tris + 9 * index;
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
@@ -377,12 +481,12 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     return minDist < s.far_clip;
 }
 
-template <bool STATS>
+template <bool STATS, bool WIDE = false>
 RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, Hit &h,
                             float &min_dist, int *stack, int stride, LaneCounters<STATS> &lc) {
     CastState cs;
-    if (castBegin<STATS>(s, q, orig, dir, t_exit, cs, lc)) castMesh<STATS>(s, orig, dir, t_exit, cs, stack, stride, lc);
-    return castEnd<STATS>(s, q, orig, dir, shadow, t_exit, cs, h, min_dist, lc);
+    if (castBegin<STATS, WIDE>(s, q, orig, dir, t_exit, cs, stack, stride, lc)) castMesh<STATS>(s, orig, dir, t_exit, cs, stack, stride, lc);
+    return castEnd<STATS, WIDE>(s, q, orig, dir, shadow, t_exit, cs, h, min_dist, lc);
 }
 
 // Sky::getColorAt, src/SceneObjects.cpp:440-445.  atan2 and acos bind to the float overloads in
@@ -674,7 +778,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
     return true;
 }
 
-template <bool STATS>
+template <bool STATS, bool WIDE = false>
 RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
     PathState st;
     Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
@@ -686,7 +790,7 @@ RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int
         float md = 0.0f;
         if (pathCasts(st, -1)) {
             pathCountRay<STATS>(st, -1, lc);
-            hit = sceneIntersect<STATS>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
+            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
         }
         if (pathConsume<STATS>(s, q, st, frames, hit, h, md, -1, color, lc)) return color;
     }

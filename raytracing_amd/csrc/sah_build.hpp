@@ -58,6 +58,17 @@ class SahBuilder {
         }
     }
 
+    // the same over ready-made boxes (leaf ~child = index of the box); centroid = middle of the box
+    explicit SahBuilder(const std::vector<SahBox> &boxes) {
+        refs_.resize(boxes.size());
+        for (size_t t = 0; t < boxes.size(); ++t) {
+            SahRef &r = refs_[t];
+            r.box = boxes[t];
+            for (int k = 0; k < 3; ++k) r.c[k] = 0.5f * (r.box.lo[k] + r.box.hi[k]);
+            r.tri = (int)t;
+        }
+    }
+
     // Fills nodes (max(nt - 1, 1) of them) and returns the depth of the deepest leaf.
     int build(std::vector<BvhNode> &nodes, int depth_limit) {
         const size_t nt = refs_.size();

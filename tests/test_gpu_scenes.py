@@ -296,12 +296,12 @@ def test_random_scenes_equal_the_oracle(hip, oracle_backend, textures, seed):
 
 
 def test_commit_rejects_lists_beyond_the_lds_staging(hip, textures):
-    for what in ("spheres", "lights", "materials"):
+    for what in ("boxes", "lights", "materials"):
         ctx = hip.create()
         mats = np.tile(hip.default_materials()[:1], (33 if what == "materials" else 4, 1))
         ctx.set_materials(mats)
-        if what == "spheres":
-            ctx.set_spheres(np.zeros((17, 3)), np.ones(17), np.zeros(17, np.int32))
+        if what == "boxes":
+            ctx.set_boxes(np.zeros((17, 3)), np.ones((17, 3)), np.zeros(17, np.int32))
         if what == "lights":
             ctx.set_lights(np.ones((9, 4)))
         ctx.set_envmap(textures["map.jpg"])
