@@ -199,19 +199,24 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
 //
 // What the walk may cull.  Sphere::rayIntersect compares dSquared = dot(L, L) - t0 * t0 with r * r,
 // where L = centre - origin; the rounding of that difference is proportional to |L|^2 (below
-// 32 * 2^-24 * |L|^2 for the operation order of sphereHit), so a ray can be accepted although it
+// 18 * 2^-24 * |L|^2 for the operation order of sphereHit: 5 from dot(L, L), 9 from t0 * t0, 4 from
+// the length of the direction), so a ray can be accepted although it
 // passes the centre at up to r + kSphereSlack * t0, t0 being the distance of its closest approach.
 // For a far, small sphere that is well outside the sphere's box.  The boxes are therefore widened
 // per ray, by delta = kSphereSlack * (largest t0 that can still matter + largest radius): no hit can
 // matter beyond the far side of the box around all spheres, nor (once a hit is known) beyond that
 // hit's distance plus a radius.
 // ---------------------------------------------------------------------------------------------
-constexpr float kSphereSlack = 2e-3f;  // > sqrt(32 * 2^-24) = 1.38e-3
+constexpr float kSphereSlack = 1.2e-3f;  // > sqrt(18 * 2^-24) = 1.04e-3
 
-// largest closest-approach distance that can matter for a ray from `orig` (no hit known yet)
-RTX_DEV float sphereReach(const DevScene &s, V3 orig) {
+// Largest closest-approach distance that can matter for a ray from `orig` (no hit known yet): the far
+// side of the box around all spheres, and for a shadow ray (t_exit > 0, just short of the light's
+// distance or the far clip) what lies beyond t_exit -- a hit out there leaves the light visible,
+// exactly as no hit does.
+RTX_DEV float sphereReach(const DevScene &s, V3 orig, float t_exit) {
     const V3 d = orig - v3(s.sphere_root_c[0], s.sphere_root_c[1], s.sphere_root_c[2]);
-    return 1.01f * (sqrtf(dot(d, d)) + s.sphere_root_h);
+    const float reach = 1.01f * (sqrtf(dot(d, d)) + s.sphere_root_h);
+    return t_exit > 0.0f ? fminf(reach, 1.02f * (t_exit + s.sphere_rmax)) : reach;
 }
 
 template <bool STATS>
@@ -231,6 +236,8 @@ RTX_DEV void sphereWalk(const DevScene &s, V3 orig, V3 dir, V3 inv, float reach,
             const float4 *np = reinterpret_cast<const float4 *>(s.sphere_bvh + cur);
             const float4 a = np[0], b = np[1], c = np[2];
             const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+            RTX_COUNT(CNT_NODE_TESTS);
+            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
             float tnL, tfL, tnR, tfR;
             {
                 float t0 = __builtin_fmaf(a.x, ix, ax), t1 = __builtin_fmaf(a.w, ix, bx);
@@ -308,7 +315,7 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     if constexpr (WIDE) {
         if (s.sphere_bvh) {
             // object_bounds holds the spheres' geometric boxes: the gate needs the same per-ray slack as the walk
-            const float reach = sphereReach(s, orig);
+            const float reach = sphereReach(s, orig, t_exit);
             const float delta = kSphereSlack * (reach + s.sphere_rmax);
             const float lo[3] = {s.object_bounds[0] - delta, s.object_bounds[1] - delta, s.object_bounds[2] - delta};
             const float hi[3] = {s.object_bounds[3] + delta, s.object_bounds[4] + delta, s.object_bounds[5] + delta};
