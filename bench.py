@@ -15,6 +15,11 @@ value = rays traced per second over the whole job, in Mrays/s; a ray is one clos
 query (one sceneIntersect call in the reference, src/Scene.cpp:29), counted by the kernel itself in
 a separate statistics pass over the same frame.
 
+--workload picks another of BASELINE.json's configurations instead (they are parity-test cases in the
+first place; the default is the line the metric is quoted on): "8k" = the same scene at 7680x4320,
+"stress" = 10 000 seeded spheres + the bunny subdivided to 1 271 808 triangles, 16384x16384, 4 samples
+per pixel (raytracing_amd/scenes.py).  No CPU baseline is timed for those.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -28,6 +33,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, DEPTH = 3840, 2160, 4
+WORKLOADS = {
+    "4k": (3840, 2160, "full default scene, 3840x2160, depth 4, 1 spp (BASELINE.json configs[3] scene at the metric's 4K size)"),
+    "8k": (7680, 4320, "full default scene, 7680x4320, depth 4, 1 spp (BASELINE.json configs[3])"),
+    "stress": (16384, 16384, "default scene with 10 000 seeded spheres and the bunny subdivided to 1 271 808 triangles, "
+                             "16384x16384, depth 4, 4 spp (BASELINE.json configs[4])"),
+}
 
 # Algorithmic FP32 operation counts per unit of work (mul, add, sub, compare-free; div, sqrt, rcp
 # count 1 each), per unit of work as the kernels do it.
@@ -166,7 +177,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
     args = ap.parse_args()
+    global WIDTH, HEIGHT
+    WIDTH, HEIGHT, workload_text = WORKLOADS[args.workload]
 
     import torch
     from raytracing_amd.distributed import ShardedRenderer
@@ -192,7 +206,11 @@ def main():
 
     def make_ctx(stats):
         ctx = hip.create(local_rank)
-        ctx.load_default_scene(textures["water"], textures["sky"])
+        if args.workload == "stress":
+            from raytracing_amd import scenes
+            scenes.load_stress_scene(ctx, hip, textures["water"], textures["sky"])
+        else:
+            ctx.load_default_scene(textures["water"], textures["sky"])
         if stats:
             ctx.set_option(OPT_STATS, 1)
         ctx.commit()
@@ -244,8 +262,9 @@ def main():
         hipapi.hipEventCreate(ctypes.byref(e0))
         hipapi.hipEventCreate(ctypes.byref(e1))
         stream = renderer.stream.cuda_stream  # the stream the kernel is launched on
-        n_launch = max(20, min(args.steps, 200))
-        for _ in range(5):
+        heavy = args.workload == "stress"  # seconds per frame
+        n_launch = max(2, min(args.steps, 5)) if heavy else max(20, min(args.steps, 200))
+        for _ in range(1 if heavy else 5):
             ctx.render_device(cam, fr, buf.data_ptr(), stream)
         hipapi.hipEventRecord(e0, ctypes.c_void_p(stream))
         for _ in range(n_launch):
@@ -263,9 +282,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 prof = json.load(open(tpath))
-                traffic = prof.get("k_render_hbm_bytes_per_launch_n%d" % world)
-                wave_insts = prof.get("k_render_valu_wave_insts_per_launch_n%d" % world)
-                lane_insts = prof.get("k_render_valu_lane_insts_per_launch_n%d" % world)
+                # (the committed counter passes are of the default workload)
+                traffic = prof.get("k_render_hbm_bytes_per_launch_n%d" % world) if args.workload == "4k" else None
+                wave_insts = prof.get("k_render_valu_wave_insts_per_launch_n%d" % world) if args.workload == "4k" else None
+                lane_insts = prof.get("k_render_valu_lane_insts_per_launch_n%d" % world) if args.workload == "4k" else None
                 if wave_insts and lane_insts:
                     # one wave64 VALU instruction occupies its SIMD for 4 clocks; 1024 SIMDs; 64 lanes/CU/clk
                     issue = {"valu_wave_insts_per_launch": int(wave_insts), "valu_lane_insts_per_launch": int(lane_insts),
@@ -278,7 +298,7 @@ def main():
         # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
         roofline = {
-            "bound": "valu", "kernel": "k_render<false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "bound": "valu", "kernel": "k_render<false, true>" if args.workload == "stress" else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
@@ -291,7 +311,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "Mrays/s (primary+secondary+shadow rays traced) & ms/frame, full scene 4K",
+            "metric": "Mrays/s (primary+secondary+shadow rays traced) & ms/frame, " + {"4k": "full scene 4K", "8k": "full scene 8K",
+                                                                                         "stress": "stress scene 16K, 4 spp"}[args.workload],
             "value": round(rays_per_frame / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,15 +321,15 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "the reference's own scene constants and assets (bunny.obj, water.jpg, envmap.jpg); no randomness",
-            "config": {"workload": "full default scene, 3840x2160, depth 4, 1 spp (BASELINE.json configs[3] scene at the "
-                                   "metric's 4K size)", "width": WIDTH, "height": HEIGHT, "depth": DEPTH,
+            "data": "the reference's own scene constants and assets (bunny.obj, water.jpg, envmap.jpg)"
+                    + ("; spheres from PCG32 seed 0x5EED" if args.workload == "stress" else "; no randomness"),
+            "config": {"workload": workload_text, "width": WIDTH, "height": HEIGHT, "depth": DEPTH,
                        "parallelism": "rows interleaved over %d GPU(s)%s" % (world, ", RCCL gather to rank 0" if world > 1 else ""),
                        "rays_per_frame": rays_per_frame, "primary": primary, "secondary": secondary, "shadow": shadow,
                        "mrays_primary_secondary": round((primary + secondary) / (ms_per_step * 1e-3) / 1e6, 2)},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "4k":
             gpu_frame = renderer.render(cam)[0]
             renderer.finish()
             torch.cuda.synchronize()
