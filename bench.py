@@ -38,6 +38,7 @@ WORKLOADS = {
     "8k": (7680, 4320, "full default scene, 7680x4320, depth 4, 1 spp (BASELINE.json configs[3])"),
     "stress": (16384, 16384, "default scene with 10 000 seeded spheres and the bunny subdivided to 1 271 808 triangles, "
                              "16384x16384, depth 4, 4 spp (BASELINE.json configs[4])"),
+    "stress4k": (4096, 4096, "the stress scene at 4096x4096, depth 4, 4 spp (a size for counter passes)"),
 }
 
 # Algorithmic FP32 operation counts per unit of work (mul, add, sub, compare-free; div, sqrt, rcp
@@ -206,7 +207,7 @@ def main():
 
     def make_ctx(stats):
         ctx = hip.create(local_rank)
-        if args.workload == "stress":
+        if args.workload.startswith("stress"):
             from raytracing_amd import scenes
             scenes.load_stress_scene(ctx, hip, textures["water"], textures["sky"])
         else:
@@ -262,7 +263,7 @@ def main():
         hipapi.hipEventCreate(ctypes.byref(e0))
         hipapi.hipEventCreate(ctypes.byref(e1))
         stream = renderer.stream.cuda_stream  # the stream the kernel is launched on
-        heavy = args.workload == "stress"  # seconds per frame
+        heavy = args.workload.startswith("stress")  # a large fraction of a second per frame, or seconds
         n_launch = max(2, min(args.steps, 5)) if heavy else max(20, min(args.steps, 200))
         for _ in range(1 if heavy else 5):
             ctx.render_device(cam, fr, buf.data_ptr(), stream)
@@ -298,7 +299,7 @@ def main():
         # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
         roofline = {
-            "bound": "valu", "kernel": "k_render<false, true>" if args.workload == "stress" else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "bound": "valu", "kernel": "k_render<false, true>" if args.workload.startswith("stress") else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
@@ -311,8 +312,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "Mrays/s (primary+secondary+shadow rays traced) & ms/frame, " + {"4k": "full scene 4K", "8k": "full scene 8K",
-                                                                                         "stress": "stress scene 16K, 4 spp"}[args.workload],
+            "metric": "Mrays/s (primary+secondary+shadow rays traced) & ms/frame, " + {"4k": "full scene 4K", "8k": "full scene 8K", "stress": "stress scene 16K, 4 spp",
+                                                                                         "stress4k": "stress scene 4K, 4 spp"}[args.workload],
             "value": round(rays_per_frame / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,7 +323,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "the reference's own scene constants and assets (bunny.obj, water.jpg, envmap.jpg)"
-                    + ("; spheres from PCG32 seed 0x5EED" if args.workload == "stress" else "; no randomness"),
+                    + ("; spheres from PCG32 seed 0x5EED" if args.workload.startswith("stress") else "; no randomness"),
             "config": {"workload": workload_text, "width": WIDTH, "height": HEIGHT, "depth": DEPTH,
                        "parallelism": "rows interleaved over %d GPU(s)%s" % (world, ", RCCL gather to rank 0" if world > 1 else ""),
                        "rays_per_frame": rays_per_frame, "primary": primary, "secondary": secondary, "shadow": shadow,

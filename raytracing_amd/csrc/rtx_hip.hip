@@ -170,8 +170,77 @@ __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &
     }
 }
 
+// offset of sample k of a pixel from its centre (RTX_OPT_SPP = 4, include/rtx.h)
+RTX_DEV float sampleDx(int k) { return k == 0 ? 0.125f : (k == 1 ? -0.375f : (k == 2 ? 0.375f : -0.125f)); }
+RTX_DEV float sampleDy(int k) { return k == 0 ? 0.375f : (k == 1 ? 0.125f : (k == 2 ? -0.125f : -0.375f)); }
+
+// Several samples per pixel, one lane per pixel: the 64 x 4 paths of a tile form a pool.  Path p is
+// sample p / 64 of pixel p % 64; every lane starts with sample 0 of its own pixel and takes the next
+// path of the pool whenever it finishes one, so the lanes stay busy until the pool is empty instead of
+// each waiting for the slowest lane's four samples.  A path's colour does not depend on the lane that
+// traces it; the colours are parked in `samples` ([sample][pixel][rgb], LDS) and summed per pixel in
+// sample order afterwards.
+template <bool STATS>
+__device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, int x0, int y0,
+                                              PathState &st, Frame *frames, float *samples, unsigned char *tile_bgr, int *stack,
+                                              LaneCounters<STATS> &lc) {
+    const unsigned lane = threadIdx.x & 63u;
+    const V3 eye = v3(cam.ox, cam.oy, cam.oz);
+    unsigned next = 0;  // wave-uniform: first path not handed out yet
+    int path = -1;      // the path this lane is tracing
+    bool active = false;
+    for (;;) {
+        // ---- hand paths to the idle lanes (a path of a pixel outside the frame is dropped at once) ----
+        while (next < 256u) {
+            const unsigned long long idle = __ballot(!active);
+            if (!idle) break;
+            if (!active) {
+                const unsigned mine = next + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (mine < 256u) {
+                    const int pixel = (int)(mine & 63u), k = (int)(mine >> 6);
+                    const int px = x0 + (pixel & 7), pk = y0 + (pixel >> 3);
+                    if (px < fr.width && pk < fr.rows) {
+                        const int row = fr.row_first + pk * fr.row_step;
+                        pathStart(st, eye, primaryDir(cam, fr.width, fr.height, row, px, sampleDx(k), sampleDy(k)), fr.depth);
+                        path = (int)mine;
+                        active = true;
+                    }
+                }
+            }
+            next += (unsigned)__popcll(idle);
+        }
+        if (!__ballot(active)) break;
+        if (active) {
+            bool hit = false;
+            Hit h;
+            float md = 0.0f;
+            if (pathCasts(st, -1)) {
+                pathCountRay<STATS>(st, -1, lc);
+                hit = sceneIntersect<STATS, true>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
+            }
+            V3 c;
+            if (pathConsume<STATS>(s, q, st, frames, hit, h, md, -1, c, lc)) {
+                float *o = samples + 3 * path;  // [sample][pixel][rgb] = 3 * (64 * sample + pixel)
+                o[0] = c.x, o[1] = c.y, o[2] = c.z;
+                active = false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (((c0 + c1) + c2) + c3) * 0.25 for this lane's own pixel
+    const float *a = samples + 3 * lane;
+    V3 sum = v3(a[0], a[1], a[2]);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) sum = sum + v3(a[192 * k], a[192 * k + 1], a[192 * k + 2]);
+    sum = sum * 0.25f;
+    unsigned char *bgr = tile_bgr + 3 * lane;
+    bgr[0] = toByte(sum.z), bgr[1] = toByte(sum.y), bgr[2] = toByte(sum.x);
+}
+
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, (STATS || WIDE) ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned *heads,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
@@ -179,6 +248,7 @@ __global__ __launch_bounds__(kBlock, (STATS || WIDE) ? 2 : 3) void k_render(DevS
     __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
+    __shared__ float s_samples[WIDE ? kBlock / 64 : 1][WIDE ? 4 * 64 * 3 : 1];  // tracePathPool: colours per sample and pixel
     loadSmallScene(q, s);
     __syncthreads();
     int *stack = s_stack + threadIdx.x;
@@ -245,6 +315,7 @@ __global__ __launch_bounds__(kBlock, (STATS || WIDE) ? 2 : 3) void k_render(DevS
         // two copies of the loop, one per mode: in the common one quad_j is the constant -1 and the quad
         // logic folds away
         if (quad) tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
+        else if (WIDE && fr.spp > 1) tracePathPool<STATS>(s, q, cam, fr, x0, y0, st, frames, s_samples[WIDE ? threadIdx.x >> 6 : 0], s_tile[threadIdx.x >> 6], stack, lc);
         else tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
         // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)

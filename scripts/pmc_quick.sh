@@ -1,5 +1,5 @@
 #!/bin/bash
-# Quick counter passes over the render kernel (bench.py, few steps).  usage: bash scripts/pmc_quick.sh <tag> ["counters of one pass" ...]
+# Quick counter passes over the render kernel (bench.py, few steps).  usage: [BENCH_ARGS="--workload stress4k"] bash scripts/pmc_quick.sh <tag> ["counters of one pass" ...]
 set -u
 TAG=${1:-q}
 shift
@@ -15,7 +15,7 @@ fi
 i=0
 for pass in "$@"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $pass -d "$OUT/p$i" -o "$TAG" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/p$i.log"; }
+  timeout -s KILL 120 rocprofv3 --pmc $pass -d "$OUT/p$i" -o "$TAG" --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/p$i.log"; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, statistics
