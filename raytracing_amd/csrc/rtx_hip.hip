@@ -87,13 +87,14 @@ constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
 // (kQuadShare) of what the whole frame would take if its work were spread evenly over all wave slots
 // -- the ones that would hold the frame up -- are entered as four quarters in quad mode, all others
 // once.  Never fewer ticks than min_ticks, never more than `cap` tiles.  out must hold n + 3 * cap
-// entries; *n_out receives the count.
+// entries; n_out[0] receives the count, n_out[1] the entry from which the tiles cost less than the
+// average tile (k_render takes those several at a time).
 constexpr float kQuadShare = 0.8f;
 __global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const unsigned *__restrict__ tiles_sorted, unsigned n,
                                unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap, unsigned *__restrict__ out,
                                unsigned *__restrict__ n_out) {
     __shared__ unsigned long long s_sum[256];
-    __shared__ unsigned s_heavy;
+    __shared__ unsigned s_heavy, s_cheap;
     unsigned long long sum = 0;
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) sum += cost_sorted[i];
     s_sum[threadIdx.x] = sum;
@@ -113,10 +114,21 @@ __global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const u
             else hi = mid;
         }
         s_heavy = lo < cap ? lo : cap;
+        const unsigned mean = (unsigned)(s_sum[0] / (n ? n : 1u));
+        lo = 0, hi = n;  // first index whose cost is below the mean
+        while (lo < hi) {
+            const unsigned mid = (lo + hi) / 2u;
+            if (cost_sorted[mid] >= mean) lo = mid + 1u;
+            else hi = mid;
+        }
+        s_cheap = lo;
     }
     __syncthreads();
     const unsigned heavy = s_heavy;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n + 3u * heavy;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        n_out[0] = n + 3u * heavy;
+        n_out[1] = 3u * heavy + (s_cheap > heavy ? s_cheap : heavy);
+    }
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned t = tiles_sorted[i];
         if (i < heavy) {
@@ -242,7 +254,7 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
-                                                   unsigned *heads,
+                                                   unsigned batch_from_arg, unsigned *heads,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
                                                    Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
@@ -257,24 +269,46 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
     // the list has one entry per tile, or four for a tile that is traced in quad mode (see kQuadFlag)
-    const unsigned n_entries = n_entries_dev ? *n_entries_dev : n_tiles;
+    const unsigned n_entries = n_entries_dev ? n_entries_dev[0] : n_tiles;
+    // entries from here on are cheap tiles (below the average cost of the previous frame, or outside every
+    // projected bounding box on the first frame of a view)
+    const unsigned batch_from = n_entries_dev ? n_entries_dev[1] : batch_from_arg;
     const unsigned my_len = lane < n_entries ? (n_entries - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
     unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
     LaneCounters<STATS> lc;
     PathState st;
     Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
+    // Taking a tile is two dependent round trips to memory (the head counter, then the list entry), a
+    // few microseconds during which the wave does nothing -- as long as a cheap tile takes to trace.  The
+    // tiles of the expensive front part of the list are taken one by one, the cheap ones behind it in
+    // batches: one atomic, the entries loaded side by side, one per lane.  A batch is at most kBatch
+    // tiles and at most a quarter of a wave's even share of the list, so that small frames (or small
+    // shares of one) keep their balance.
+    constexpr unsigned kBatch = 8;
+    const unsigned even_share = n_entries / (gridDim.x * (kBlock / 64u));
+    const unsigned batch_max = even_share / 4u < 1u ? 1u : (even_share / 4u > kBatch ? kBatch : even_share / 4u);
+    bool cheap_zone = batch_from == 0u;  // wave-uniform: the queue position last seen lies in the cheap part
+    unsigned batch = 0xffffffffu;        // lane k: entry k of the batch in hand
+    unsigned batch_n = 0, batch_k = 0;   // wave-uniform: its size, the next one to trace
     for (;;) {
         // ---- take a tile ----
         unsigned tile = 0xffffffffu;
-        for (;;) {
+        if (batch_k < batch_n) tile = __builtin_amdgcn_readlane(batch, batch_k++);
+        else for (;;) {
             const unsigned len = __builtin_amdgcn_readlane(my_len, qi);
+            const unsigned want = cheap_zone ? batch_max : 1u;
             unsigned i = len;
-            if (lane == 0 && len) i = atomicAdd(heads + qi * kHeadStride, 1u);
+            if (lane == 0 && len) i = atomicAdd(heads + qi * kHeadStride, want);
             i = __builtin_amdgcn_readfirstlane(i);
             if (i < len) {
-                const unsigned e = qi + i * kQueues;
-                tile = order ? order[e] : e;
+                const unsigned n = want < len - i ? want : len - i;
+                const unsigned e = qi + (i + lane) * kQueues;
+                batch = 0xffffffffu;
+                if (lane < n) batch = order ? order[e] : e;
+                batch_n = n, batch_k = 1u;
+                cheap_zone = qi + (i + n) * kQueues >= batch_from;
+                tile = __builtin_amdgcn_readlane(batch, 0);
                 break;
             }
             // this queue is empty: every lane looks at one head, the wave moves to the next queue
@@ -487,6 +521,7 @@ struct rtx_ctx {
     unsigned *d_order = nullptr;
     size_t d_order_cap = 0;
     std::vector<unsigned char> order_key;
+    unsigned order_cheap_from = 0;  // position in d_order from which the tiles see none of the projected boxes
     // schedule feedback: per-tile cost of the last frame, and the tile list sorted by it
     int feedback = 1;                  // RTX_OPT_SCHEDULE_FEEDBACK
     int quad_mode = 1;                 // RTX_OPT_QUAD
@@ -592,9 +627,12 @@ bool projectBox(const rtx_camera *cam, int W, int H, const float lo[3], const fl
 // glass sphere, then the rest -- a longest-job-first schedule from bounding boxes alone.  The frame
 // takes as long as its slowest wave; a wave that walks the mesh at every bounce runs for hundreds of
 // microseconds, and if it only starts halfway through the dispatch the chip idles waiting for it.
+// *cheap_from = the list position from which the tiles see none of the boxes (with the natural order:
+// 0 when there are no boxes at all, the end of the list when the mesh may be anywhere).
 int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int blocks_x, int blocks_y,
-              const unsigned **out) {
+              const unsigned **out, unsigned *cheap_from) {
     *out = nullptr;
+    *cheap_from = 0;
     const size_t n = (size_t)blocks_x * blocks_y;
     std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame) + sizeof(int));
     memcpy(key.data(), cam, sizeof(rtx_camera));
@@ -602,6 +640,7 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
     memcpy(key.data() + sizeof(rtx_camera) + sizeof(rtx_frame), &bt, sizeof(int));
     if (key == c->order_key && c->d_order) {
         *out = c->d_order;
+        *cheap_from = c->order_cheap_from;
         return RTX_OK;
     }
     struct Rect {
@@ -614,7 +653,10 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
         Rect r;
         r.cls = 0;
         if (projectBox(cam, f->width, f->height, d.mesh_lo, d.mesh_hi, r.r)) rects.push_back(r);
-        else return RTX_OK;  // the mesh may be anywhere on screen: keep the natural order
+        else {  // the mesh may be anywhere on screen: keep the natural order, no tile counts as cheap
+            *cheap_from = (unsigned)n;
+            return RTX_OK;
+        }
     }
     for (size_t i = 0; i < c->spheres.size() && !c->big_spheres; ++i) {  // (a large set is everywhere: no classes from it)
         const Material &m = c->materials[c->sphere_mat[i]];
@@ -650,7 +692,9 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
     HIP_OR_FAIL(hipDeviceSynchronize());
     HIP_OR_FAIL(hipMemcpy(c->d_order, all.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
     c->order_key = key;
+    c->order_cheap_from = (unsigned)(order[0].size() + order[1].size());
     *out = c->d_order;
+    *cheap_from = c->order_cheap_from;
     return RTX_OK;
 }
 
@@ -669,7 +713,7 @@ int scheduleBuffers(rtx_ctx *c, size_t n) {
     c->d_sort_tmp = nullptr, c->d_entries = nullptr, c->sched_cap = 0;
     c->cost_key.clear(), c->by_cost_key.clear();
     for (unsigned **b : bufs) HIP_OR_FAIL(hipMalloc((void **)b, n * sizeof(unsigned)));
-    HIP_OR_FAIL(hipMalloc((void **)&c->d_entries, (4 * n + 1) * sizeof(unsigned)));
+    HIP_OR_FAIL(hipMalloc((void **)&c->d_entries, (4 * n + 2) * sizeof(unsigned)));
     std::vector<unsigned> iota(n);
     for (size_t i = 0; i < n; ++i) iota[i] = (unsigned)i;
     HIP_OR_FAIL(hipMemcpy(c->d_iota, iota.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -705,20 +749,21 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     // single frame: a camera that moves every frame stays on the static order.)
     bool sort_now = false;
     const unsigned *n_entries_dev = nullptr;
-    unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;
+    unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;  // [0] entries, [1] where the cheap ones begin
+    unsigned batch_from = 0;
     if (c->feedback && key == c->by_cost_key) {
         order = c->d_entries, n_entries_dev = d_n_entries;
     } else if (c->feedback && key == c->cost_key) {
         order = c->d_entries, n_entries_dev = d_n_entries;
         sort_now = true;
-    } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order)) {
+    } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order, &batch_from)) {
         return e;
     }
     // blocks that are resident at once: the kernel is a loop over tiles, more blocks would only queue
     // the general build of the kernel only where it is needed: a large sphere set, several samples per pixel
     const bool wide = c->big_spheres || c->spp > 1;
-    using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned *, unsigned *,
-                                  unsigned char *, Counters *);
+    using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
+                                  unsigned *, unsigned char *, Counters *);
     const RenderKernel kernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     int &resident = c->resident_blocks[variant];
@@ -748,7 +793,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         c->by_cost_key = key;
     }
     hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
-                       order, n_entries_dev, c->d_heads, c->d_cost, d_out, c->d_counters);
+                       order, n_entries_dev, batch_from, c->d_heads, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
     c->cost_key = key;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
