@@ -109,12 +109,13 @@ enum rtx_option {
                                  for meshes up to 262 144 triangles, Morton order on the GPU above;
                                  1 = always Morton order on the GPU; 2 = always surface-area
                                  heuristic.  The tree only steers the walk: results do not change */
-    RTX_OPT_SCHEDULE_FEEDBACK = 7, /* 0/1 (default 1): the second frame of a view (same camera and
-                                 frame description) starts its tiles in the order of what they
-                                 cost in the first; 0 = always the static order from projected
-                                 bounding boxes.  Scheduling only: pixels do not change             */
+    RTX_OPT_SCHEDULE_FEEDBACK = 7, /* 0/1 (default 1): a frame whose camera is the previous frame's or
+                                 close to it (and whose frame description is the same) starts its
+                                 tiles in the order of what they cost in that frame; 0 = always the
+                                 static order from projected bounding boxes.  Scheduling only: pixels
+                                 do not change                                                       */
     RTX_OPT_QUAD = 8,         /* 0/1/2 (default 1): with schedule feedback, tiles that lasted long in
-                                 the previous frame of the view are traced with four lanes per pixel
+                                 the previous frame are traced with four lanes per pixel
                                  (the shadow rays of a node go out side by side): 0 never, 1 the tiles
                                  that would hold the frame up, 2 every tile.  Pixels do not change   */
     RTX_OPT_SPP = 9,          /* 1 (default) or 4: samples per pixel.  No counterpart in the reference

@@ -83,58 +83,134 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
 constexpr unsigned kQueues = 64, kHeadStride = 32;
 constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
 
-// After the tiles have been sorted by last frame's cost: those that lasted longer than a share
-// (kQuadShare) of what the whole frame would take if its work were spread evenly over all wave slots
-// -- the ones that would hold the frame up -- are entered as four quarters in quad mode, all others
-// once.  Never fewer ticks than min_ticks, never more than `cap` tiles.  out must hold n + 3 * cap
-// entries; n_out[0] receives the count, n_out[1] the entry from which the tiles cost less than the
-// average tile (k_render takes those several at a time).
+// Quad mode is for the tiles that lasted longer in the previous frame than a share (kQuadShare) of what
+// the whole frame would take if its work were spread evenly over all wave slots -- the ones that would
+// hold the frame up: they are entered as four quarters, all others once.  Never tiles shorter than
+// min_ticks, never more than `cap` tiles.
 constexpr float kQuadShare = 0.8f;
-__global__ void k_expand_order(const unsigned *__restrict__ cost_sorted, const unsigned *__restrict__ tiles_sorted, unsigned n,
-                               unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap, unsigned *__restrict__ out,
-                               unsigned *__restrict__ n_out) {
-    __shared__ unsigned long long s_sum[256];
-    __shared__ unsigned s_heavy, s_cheap;
-    unsigned long long sum = 0;
-    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) sum += cost_sorted[i];
-    s_sum[threadIdx.x] = sum;
-    __syncthreads();
-    for (unsigned off = blockDim.x / 2u; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
-        __syncthreads();
+
+// The tile list of a frame from the costs of the previous one, without a sort: the tiles are dealt into
+// bins by cost on a logarithmic scale of eight steps per octave, most expensive first.  The bins above
+// the quad-mode threshold (to the nearest bin edge) are entered as quarters (out must hold n + 3 * cap entries),
+// the position from which the bins lie below the average cost is reported for k_render's batches.
+// Inside a bin the order is whatever the atomics make it; the bins are narrow enough (9 %) for the
+// queues to balance as well as with the exact order.  Three small launches (histogram per workgroup,
+// scan, scatter), a few tens of microseconds: cheap enough to run for every frame of a moving camera.
+constexpr unsigned kCostBins = 256, kBinBlocks = 64, kBinThreads = 1024;
+RTX_DEV unsigned costBin(unsigned cost) {  // descending: bin 0 holds the most expensive tiles
+    const unsigned bits = __float_as_uint((float)cost) >> 20;  // exponent and three mantissa bits
+    const unsigned b = bits > (127u << 3) ? bits - (127u << 3) : 0u;
+    return kCostBins - 1u - (b < kCostBins ? b : kCostBins - 1u);
+}
+// atomicAdd(&counters[bin], 1) for every lane with `valid`; returns the lane's own old value.  Most
+// tiles of a frame fall into a handful of bins (sky, water), and 64 atomics on one LDS address go one
+// after the other: the lanes that share the bin of the first lane (two rounds of that) use one atomic
+// together, whoever is left adds for itself.  Must be called by all lanes of the wave together.
+RTX_DEV unsigned binSlot(unsigned *counters, unsigned bin, bool valid) {
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned slot = 0;
+    unsigned long long todo = __ballot(valid);
+    for (int round = 0; round < 2 && todo; ++round) {
+        const unsigned leader = (unsigned)__builtin_ctzll(todo);
+        const unsigned lb = __builtin_amdgcn_readlane(bin, leader);
+        const unsigned long long same = __ballot(valid && bin == lb) & todo;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&counters[lb], (unsigned)__popcll(same));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if ((same >> lane) & 1ull) slot = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
     }
-    if (threadIdx.x == 0) {
-        const float even = (float)s_sum[0] / (float)(wave_slots ? wave_slots : 1u);
+    if ((todo >> lane) & 1ull) slot = atomicAdd(&counters[bin], 1u);
+    return slot;
+}
+// workgroup g owns tiles [g * per, (g + 1) * per)
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(const unsigned *__restrict__ cost, unsigned n, unsigned per,
+                                                           unsigned *__restrict__ block_hist, unsigned long long *__restrict__ block_sum) {
+    __shared__ unsigned s_hist[kCostBins];
+    __shared__ unsigned long long s_sum[kBinThreads / 64];
+    const unsigned t = threadIdx.x, first = blockIdx.x * per, last = first + per < n ? first + per : n;
+    for (unsigned b = t; b < kCostBins; b += kBinThreads) s_hist[b] = 0u;
+    __syncthreads();
+    unsigned long long sum = 0;
+    for (unsigned base = first; base < last; base += kBinThreads) {
+        const unsigned i = base + t;
+        const bool valid = i < last;
+        const unsigned cst = valid ? cost[i] : 0u;
+        sum += cst;
+        binSlot(s_hist, costBin(cst), valid);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((t & 63u) == 0u) s_sum[t >> 6] = sum;
+    __syncthreads();
+    for (unsigned b = t; b < kCostBins; b += kBinThreads) block_hist[blockIdx.x * kCostBins + b] = s_hist[b];
+    if (t == 0) {
+        unsigned long long total = 0;
+        for (unsigned w = 0; w < kBinThreads / 64; ++w) total += s_sum[w];
+        block_sum[blockIdx.x] = total;
+    }
+}
+// one workgroup of kCostBins threads: block_hist[g][b] becomes the list position at which workgroup g
+// starts to write its tiles of bin b; head = {entries, first cheap entry, quad-mode tiles, quad-mode bins}
+__global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ block_hist, const unsigned long long *__restrict__ block_sum,
+                                                        unsigned n, unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap,
+                                                        unsigned *__restrict__ n_out, unsigned *__restrict__ head) {
+    __shared__ unsigned s_total[kCostBins], s_start[kCostBins];
+    const unsigned b = threadIdx.x;
+    unsigned at = 0;
+    for (unsigned g = 0; g < kBinBlocks; ++g) {
+        const unsigned c = block_hist[g * kCostBins + b];
+        block_hist[g * kCostBins + b] = at;
+        at += c;
+    }
+    s_total[b] = at;
+    __syncthreads();
+    if (b == 0) {
+        unsigned long long sum = 0;
+        for (unsigned g = 0; g < kBinBlocks; ++g) sum += block_sum[g];
+        const float even = (float)sum / (float)(wave_slots ? wave_slots : 1u);
         const float share = quad_share * even;
         const unsigned limit = share > (float)min_ticks ? (unsigned)share : min_ticks;
-        unsigned lo = 0, hi = n;  // first index whose cost is below the limit (costs descend)
-        while (lo < hi) {
-            const unsigned mid = (lo + hi) / 2u;
-            if (cost_sorted[mid] >= limit) lo = mid + 1u;
-            else hi = mid;
+        const unsigned mean = (unsigned)(sum / (n ? n : 1u));
+        // quad mode for the bins at or above the limit's, as long as that stays within `cap` tiles
+        const unsigned limit_bin = costBin(limit);
+        unsigned heavy = 0, heavy_bins = 0;
+        for (; heavy_bins <= limit_bin && heavy_bins < kCostBins; ++heavy_bins) {
+            if (heavy + s_total[heavy_bins] > cap) break;
+            heavy += s_total[heavy_bins];
         }
-        s_heavy = lo < cap ? lo : cap;
-        const unsigned mean = (unsigned)(s_sum[0] / (n ? n : 1u));
-        lo = 0, hi = n;  // first index whose cost is below the mean
-        while (lo < hi) {
-            const unsigned mid = (lo + hi) / 2u;
-            if (cost_sorted[mid] >= mean) lo = mid + 1u;
-            else hi = mid;
+        unsigned pos = 0, cheap_from = n;
+        const unsigned mean_bin = costBin(mean);
+        for (unsigned k = 0; k < kCostBins; ++k) {
+            if (k == mean_bin + 1u) cheap_from = pos;
+            s_start[k] = pos, pos += s_total[k];
         }
-        s_cheap = lo;
+        if (cheap_from < heavy) cheap_from = heavy;
+        n_out[0] = n + 3u * heavy;
+        n_out[1] = 3u * heavy + cheap_from;
+        head[0] = heavy, head[1] = heavy_bins;
     }
     __syncthreads();
-    const unsigned heavy = s_heavy;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        n_out[0] = n + 3u * heavy;
-        n_out[1] = 3u * heavy + (s_cheap > heavy ? s_cheap : heavy);
-    }
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned t = tiles_sorted[i];
-        if (i < heavy) {
-            for (unsigned sub = 0; sub < 4u; ++sub) out[4u * i + sub] = t | (sub << 28) | kQuadFlag;
-        } else {
-            out[3u * heavy + i] = t;
+    for (unsigned g = 0; g < kBinBlocks; ++g) block_hist[g * kCostBins + b] += s_start[b];
+}
+__global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const unsigned *__restrict__ cost, unsigned n, unsigned per,
+                                                             const unsigned *__restrict__ block_base, const unsigned *__restrict__ head,
+                                                             unsigned *__restrict__ out) {
+    __shared__ unsigned s_cursor[kCostBins];
+    const unsigned t = threadIdx.x, first = blockIdx.x * per, last = first + per < n ? first + per : n;
+    for (unsigned b = t; b < kCostBins; b += kBinThreads) s_cursor[b] = block_base[blockIdx.x * kCostBins + b];
+    __syncthreads();
+    const unsigned heavy = head[0], heavy_bins = head[1];
+    for (unsigned base = first; base < last; base += kBinThreads) {
+        const unsigned i = base + t;
+        const bool valid = i < last;
+        const unsigned b = costBin(valid ? cost[i] : 0u);
+        const unsigned pos = binSlot(s_cursor, b, valid);
+        if (valid) {
+            if (b < heavy_bins) {
+                for (unsigned sub = 0; sub < 4u; ++sub) out[4u * pos + sub] = i | (sub << 28) | kQuadFlag;
+            } else {
+                out[3u * heavy + pos] = i;
+            }
         }
     }
 }
@@ -525,11 +601,15 @@ struct rtx_ctx {
     // schedule feedback: per-tile cost of the last frame, and the tile list sorted by it
     int feedback = 1;                  // RTX_OPT_SCHEDULE_FEEDBACK
     int quad_mode = 1;                 // RTX_OPT_QUAD
-    unsigned *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_order_by_cost = nullptr;
-    unsigned *d_entries = nullptr;     // d_order_by_cost with the longest tiles split into quarters; [cap] = entry count
-    void *d_sort_tmp = nullptr;
-    size_t sched_cap = 0, sort_tmp_bytes = 0;
-    std::vector<unsigned char> cost_key, by_cost_key;  // the (camera, frame) the costs / the sorted list belong to
+    unsigned *d_cost = nullptr;        // per tile: what it cost in the last frame (100 MHz ticks)
+    unsigned *d_entries = nullptr;     // the tile list built from it, the longest tiles as four quarters; then {entries, first cheap entry}
+    unsigned *d_bins = nullptr;        // k_bin_*: per-workgroup histograms, then two words of header
+    unsigned long long *d_bin_sums = nullptr;
+    size_t sched_cap = 0;
+    bool have_cost = false;            // d_cost holds the costs of a frame: of cost_frame under cost_cam
+    rtx_camera cost_cam{};
+    rtx_frame cost_frame{};
+    std::vector<unsigned char> by_cost_key;  // the (camera, frame) the list was built for
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -698,32 +778,39 @@ int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int
     return RTX_OK;
 }
 
-// Buffers of the schedule feedback, sized for n tiles: cost per tile, the sorted copy, the identity
-// list the sort permutes, the resulting order, and the sort's scratch space.
+// Buffers of the schedule feedback, sized for n tiles: cost per tile and the list built from it.
 int scheduleBuffers(rtx_ctx *c, size_t n) {
     if (n <= c->sched_cap) return RTX_OK;
     HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old buffers
-    unsigned **bufs[] = {&c->d_cost, &c->d_cost_sorted, &c->d_iota, &c->d_order_by_cost};
-    for (unsigned **b : bufs) {
-        (void)hipFree(*b);
-        *b = nullptr;
-    }
-    (void)hipFree(c->d_sort_tmp);
+    (void)hipFree(c->d_cost);
     (void)hipFree(c->d_entries);
-    c->d_sort_tmp = nullptr, c->d_entries = nullptr, c->sched_cap = 0;
-    c->cost_key.clear(), c->by_cost_key.clear();
-    for (unsigned **b : bufs) HIP_OR_FAIL(hipMalloc((void **)b, n * sizeof(unsigned)));
+    c->d_cost = nullptr, c->d_entries = nullptr, c->sched_cap = 0;
+    c->have_cost = false, c->by_cost_key.clear();
+    HIP_OR_FAIL(hipMalloc((void **)&c->d_cost, n * sizeof(unsigned)));
     HIP_OR_FAIL(hipMalloc((void **)&c->d_entries, (4 * n + 2) * sizeof(unsigned)));
-    std::vector<unsigned> iota(n);
-    for (size_t i = 0; i < n; ++i) iota[i] = (unsigned)i;
-    HIP_OR_FAIL(hipMemcpy(c->d_iota, iota.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
     HIP_OR_FAIL(hipMemset(c->d_cost, 0, n * sizeof(unsigned)));
-    c->sort_tmp_bytes = 0;
-    HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
-                                                             c->d_order_by_cost, (int)n, 0, 32, nullptr));
-    HIP_OR_FAIL(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
     c->sched_cap = n;
     return RTX_OK;
+}
+
+// Is `cam` close enough to the camera of the frame whose tile costs are in hand for those costs to say
+// where this frame's expensive tiles are?  (Same projection, the basis turned by a few degrees at
+// most, the origin moved by a few per cent of its distance to the scene.)
+bool nearbyView(const rtx_ctx *c, const rtx_camera *cam) {
+    const rtx_camera &o = c->cost_cam;
+    if (cam->tan_half_fov != o.tan_half_fov || cam->add_origin != o.add_origin) return false;
+    for (int k = 0; k < 9; ++k)
+        if (!(std::fabs(cam->basis[k] - o.basis[k]) <= 0.05f)) return false;
+    const float *b = c->dev.object_bounds;
+    float dist2 = 0.0f, move2 = 0.0f, size2 = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+        const bool bounded = b[k] <= b[3 + k];
+        const float centre = bounded ? 0.5f * (b[k] + b[3 + k]) : 0.0f, half = bounded ? 0.5f * (b[3 + k] - b[k]) : 0.0f;
+        dist2 += (cam->origin[k] - centre) * (cam->origin[k] - centre);
+        move2 += (cam->origin[k] - o.origin[k]) * (cam->origin[k] - o.origin[k]);
+        size2 += half * half;
+    }
+    return move2 <= 0.05f * 0.05f * (dist2 + size2);
 }
 
 // enqueue one render on `stream`; output rows * width * 3 bytes at d_out.  The queue heads, the
@@ -742,20 +829,20 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame));
     memcpy(key.data(), cam, sizeof(rtx_camera));
     memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
-    // Longest tiles first.  The first frame of a view goes by classes from projected bounding boxes
-    // (tileOrder); every frame records what each tile cost, and the second frame of the same view
-    // sorts the tiles by that, on the device and in stream order, after which the list is kept until
-    // the view changes.  (The sort and the list expansion take 0.05-0.15 ms, more than they gain on a
-    // single frame: a camera that moves every frame stays on the static order.)
-    bool sort_now = false;
+    // Longest tiles first.  Every frame records what each of its tiles cost.  A frame of the same frame
+    // description whose camera is the previous frame's or close to it gets its list from those costs
+    // (k_bin_*: three small launches in stream order, about 25 us), and a frame of exactly the same view
+    // as the one the list was built for reuses the list.  Anything else -- the first frame, a cut to
+    // another view -- goes by classes from projected bounding boxes (tileOrder).
+    bool list_now = false;
     const unsigned *n_entries_dev = nullptr;
     unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;  // [0] entries, [1] where the cheap ones begin
     unsigned batch_from = 0;
     if (c->feedback && key == c->by_cost_key) {
         order = c->d_entries, n_entries_dev = d_n_entries;
-    } else if (c->feedback && key == c->cost_key) {
+    } else if (c->feedback && c->have_cost && memcmp(f, &c->cost_frame, sizeof(rtx_frame)) == 0 && nearbyView(c, cam)) {
         order = c->d_entries, n_entries_dev = d_n_entries;
-        sort_now = true;
+        list_now = true;
     } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order, &batch_from)) {
         return e;
     }
@@ -779,23 +866,25 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
-    if (sort_now) {
-        // by exact cost: with coarser keys the queues end up less evenly loaded
-        HIP_OR_FAIL(hipcub::DeviceRadixSort::SortPairsDescending(c->d_sort_tmp, c->sort_tmp_bytes, c->d_cost, c->d_cost_sorted, c->d_iota,
-                                                                 c->d_order_by_cost, (int)n_tiles, 0, 32, stream));
+    if (list_now) {
         // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.1 ms,
         // never more than an eighth of all), 2 every tile
         const unsigned cap = c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
-        hipLaunchKernelGGL(k_expand_order, dim3(64), dim3(256), 0, stream, c->d_cost_sorted, c->d_order_by_cost, (unsigned)n_tiles,
+        const unsigned per = (unsigned)((n_tiles + kBinBlocks - 1) / kBinBlocks);
+        unsigned *const d_head = c->d_bins + kBinBlocks * kCostBins;
+        hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, c->d_bin_sums);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, c->d_bins, c->d_bin_sums, (unsigned)n_tiles,
                            (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 10000u, cap,
-                           c->d_entries, d_n_entries);
+                           d_n_entries, d_head);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, d_head,
+                           c->d_entries);
         HIP_OR_FAIL(hipGetLastError());
         c->by_cost_key = key;
     }
     hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
                        order, n_entries_dev, batch_from, c->d_heads, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
-    c->cost_key = key;
+    c->cost_cam = *cam, c->cost_frame = *f, c->have_cost = true;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return RTX_OK;
@@ -821,7 +910,9 @@ int rtx_create(rtx_ctx **out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_heads, kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess) {
+        (e = hipMalloc((void **)&c->d_heads, kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_bins, (kBinBlocks * kCostBins + 2) * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
         delete c;
         return failHip(e, "rtx_create");
     }
@@ -836,13 +927,11 @@ void rtx_destroy(rtx_ctx *c) {
     for (void *p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_heads);
+    (void)hipFree(c->d_bins);
+    (void)hipFree(c->d_bin_sums);
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_cost);
-    (void)hipFree(c->d_cost_sorted);
-    (void)hipFree(c->d_iota);
-    (void)hipFree(c->d_order_by_cost);
     (void)hipFree(c->d_entries);
-    (void)hipFree(c->d_sort_tmp);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -868,7 +957,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_SPP:
             if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
             c->spp = (int)value;
-            c->cost_key.clear(), c->by_cost_key.clear();  // what a tile costs changes with it
+            c->have_cost = false, c->by_cost_key.clear();  // what a tile costs changes with it
             break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
