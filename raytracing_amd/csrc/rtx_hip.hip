@@ -330,7 +330,7 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
-                                                   unsigned batch_from_arg, unsigned *heads,
+                                                   unsigned batch_from_arg, unsigned *heads, unsigned *heads_next,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
                                                    Counters *counters) {
     __shared__ int s_stack[kStackDepth * kBlock];
@@ -341,6 +341,9 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     __syncthreads();
     int *stack = s_stack + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
+    // the queue heads come in two sets: this launch counts in one and clears the other for the next
+    // launch of the context (launches of a context follow one another), which saves a fill per frame
+    if (blockIdx.x == 0 && threadIdx.x < kQueues) heads_next[threadIdx.x * kHeadStride] = 0u;
     // rows of whole dwords: a finished tile goes out as 48 dword stores instead of 192 byte stores
     const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
@@ -589,7 +592,8 @@ struct rtx_ctx {
     std::vector<void *> owned;
     int bvh_depth = 0;
     Counters *d_counters = nullptr;
-    unsigned *d_heads = nullptr;      // work-queue heads of k_render
+    unsigned *d_heads = nullptr;      // work-queue heads of k_render, two sets: a launch counts in one and clears the other
+    bool heads_flip = false;
     int resident_blocks[4] = {0, 0, 0, 0};  // grid size of k_render<STATS, WIDE>, index STATS + 2 * WIDE
     int spp = 1;                            // RTX_OPT_SPP
     bool big_spheres = false;               // more spheres than the LDS staging holds: they sit behind a BVH
@@ -850,7 +854,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     // the general build of the kernel only where it is needed: a large sphere set, several samples per pixel
     const bool wide = c->big_spheres || c->spp > 1;
     using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
-                                  unsigned *, unsigned char *, Counters *);
+                                  unsigned *, unsigned *, unsigned char *, Counters *);
     const RenderKernel kernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     int &resident = c->resident_blocks[variant];
@@ -865,7 +869,8 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
-    HIP_OR_FAIL(hipMemsetAsync(c->d_heads, 0, kQueues * kHeadStride * sizeof(unsigned), stream));
+    unsigned *const heads = c->d_heads + (c->heads_flip ? kQueues * kHeadStride : 0u);
+    unsigned *const heads_next = c->d_heads + (c->heads_flip ? 0u : kQueues * kHeadStride);
     if (list_now) {
         // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.1 ms,
         // never more than an eighth of all), 2 every tile
@@ -882,8 +887,9 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         c->by_cost_key = key;
     }
     hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
-                       order, n_entries_dev, batch_from, c->d_heads, c->d_cost, d_out, c->d_counters);
+                       order, n_entries_dev, batch_from, heads, heads_next, c->d_cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
+    c->heads_flip = !c->heads_flip;  // only now: a launch that failed has cleared nothing
     c->cost_cam = *cam, c->cost_frame = *f, c->have_cost = true;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -910,7 +916,8 @@ int rtx_create(rtx_ctx **out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_heads, kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_heads, 2 * kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->d_heads, 0, 2 * kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_bins, (kBinBlocks * kCostBins + 2) * sizeof(unsigned))) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
         delete c;

@@ -114,8 +114,8 @@ def test_stress_scene_rows_equal_the_oracle(hip, oracle_backend, textures, size,
     subdivided to 1 271 808 triangles, 16384 x 16384 pixels, 4 samples per pixel -- rendered whole on
     the GPU; the oracle renders a few full-width rows of it (through the sphere cloud, through the
     top of the mesh; the smaller edition also through its widest part) and those rows are equal byte
-    for byte.  A smaller edition of the same scene runs first.  The whole frame is then rendered again as two row-interleaved halves, as two
-    ranks would: the same frame."""
+    for byte.  A smaller edition of the same scene runs first.  The whole frame is then rendered again
+    as two row-interleaved halves, as two ranks would: the same frame."""
     hip_ctx = hip.create()
     nt = scenes.load_stress_scene(hip_ctx, hip, textures["water"], textures["envmap.jpg"], levels, n_spheres)
     assert nt == 4968 * 4 ** levels
