@@ -164,7 +164,7 @@ def test_ray_counts_match_oracle(hip, oracle_backend, textures):
 
 @pytest.mark.parametrize("quad", [0, 1, 2])
 def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_frames, golden_small, quad):
-    """The first frame of a view runs in the static tile order, the second sorts the tiles by what they
+    """The first frame of a view runs in the static tile order, the second lists the tiles by what they
     cost and (RTX_OPT_QUAD) traces the expensive ones -- here: none / some / all -- with four lanes per
     pixel.  Every frame must be the reference's G1 frame, with the same ray counts."""
     cfg = golden_frames["G1"]
@@ -180,20 +180,26 @@ def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_fra
     assert counts[0] == (st.primary_rays, st.secondary_rays, st.shadow_rays, st.sky_lookups, st.lit_lights)
 
 
-def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures):
-    """A camera that stands still, moves, stands still, moves on: frames are scheduled by the static
-    classes, by their own view's costs, or by another view's list (renewed every few frames).  None of
+@pytest.mark.parametrize("quad", [1, 2])
+def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures, quad):
+    """A camera that stands still, moves a little per frame, stands still, jumps somewhere else and back,
+    and a change of frame size in between: frames are scheduled by the static classes (first frame, a
+    cut), by the previous frame's costs (a nearby view) or by the kept list (the same view).  None of
     that may show in the pixels."""
-    ctx = make_default_context(hip, textures, sky="map.jpg")
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad)])
     octx = make_default_context(oracle_backend, textures, sky="map.jpg")
     cam = hip.default_camera()
-    for step in (0, 0, 1, 2, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
-        cam.origin[0] = -7.5 + 0.4 * step
-        cam.origin[2] = -5.0 - 0.3 * step
-        a = ctx.render(cam, 320, 240, 4)
-        ocam = oracle_backend.default_camera()
-        ocam.origin[0], ocam.origin[2] = cam.origin[0], cam.origin[2]
-        assert np.array_equal(a, octx.render(ocam, 320, 240, 4))
+    ocam = oracle_backend.default_camera()
+    x0, z0 = cam.origin[0], cam.origin[2]
+    #        (step, jump, width, height)
+    shots = [(0, 0, 320, 240), (0, 0, 320, 240), (1, 0, 320, 240), (2, 0, 320, 240), (3, 0, 320, 240), (3, 0, 320, 240),
+             (3, 0, 320, 240), (4, 0, 320, 240), (5, 1, 320, 240), (6, 0, 320, 240), (7, 0, 200, 120), (8, 0, 200, 120),
+             (8, 1, 200, 120), (8, 0, 200, 120), (9, 0, 320, 240), (10, 0, 320, 240)]
+    for step, jump, w, h in shots:
+        for c in (cam, ocam):
+            c.origin[0] = x0 + 0.4 * step + (25.0 if jump else 0.0)
+            c.origin[2] = z0 - 0.3 * step + (12.0 if jump else 0.0)
+        assert np.array_equal(ctx.render(cam, w, h, 4), octx.render(ocam, w, h, 4)), (step, jump, w, h)
 
 
 def test_deterministic(hip, textures):
