@@ -872,14 +872,14 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     unsigned *const heads = c->d_heads + (c->heads_flip ? kQueues * kHeadStride : 0u);
     unsigned *const heads_next = c->d_heads + (c->heads_flip ? 0u : kQueues * kHeadStride);
     if (list_now) {
-        // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.1 ms,
+        // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.2 ms,
         // never more than an eighth of all), 2 every tile
         const unsigned cap = c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
         const unsigned per = (unsigned)((n_tiles + kBinBlocks - 1) / kBinBlocks);
         unsigned *const d_head = c->d_bins + kBinBlocks * kCostBins;
         hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, c->d_bin_sums);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, c->d_bins, c->d_bin_sums, (unsigned)n_tiles,
-                           (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 10000u, cap,
+                           (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 20000u, cap,
                            d_n_entries, d_head);
         hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, d_head,
                            c->d_entries);
