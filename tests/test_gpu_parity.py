@@ -209,3 +209,30 @@ def test_deterministic(hip, textures):
     b = ctx.render(cam, 640, 360, 4)
     c = make_default_context(hip, textures, sky="map.jpg").render(cam, 640, 360, 4)
     assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("quad", [0, 1, 2])
+@pytest.mark.parametrize("size", [(331, 207), (640, 360)])
+def test_every_frame_writes_every_pixel(hip, oracle_backend, textures, quad, size):
+    """The frame buffer is overwritten with a pattern before every render: whatever list a frame is
+    scheduled by (static classes, cost bins with quad-mode quarters, the kept list, a nearby view's
+    costs), every tile must be on it -- a tile left out would show the pattern, not an old frame."""
+    import torch
+    from raytracing_amd.rtx import Frame
+    w, h = size
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad)])
+    octx = make_default_context(oracle_backend, textures, sky="map.jpg")
+    cam, ocam = hip.default_camera(), oracle_backend.default_camera()
+    x0 = cam.origin[0]
+    buf = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    want = {}
+    for shift in (0, 0, 0, 1, 2, 2, 0):
+        cam.origin[0] = ocam.origin[0] = x0 + 0.25 * shift
+        buf.fill_(0xA5)
+        torch.cuda.synchronize()
+        ctx.render_device(cam, Frame(w, h, 4, 0, 1), buf.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        if shift not in want:
+            want[shift] = octx.render(ocam, w, h, 4)
+        assert np.array_equal(buf.cpu().numpy().reshape(h, w, 3), want[shift]), shift
