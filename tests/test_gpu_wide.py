@@ -138,3 +138,24 @@ def test_stress_scene_rows_equal_the_oracle(hip, oracle_backend, textures, size,
     # a second and third frame of the same view (cost-sorted order, quad tiles; kept list)
     for _ in range(2):
         assert np.array_equal(hip_ctx.render(cam, size, size, 4), frame)
+
+
+@pytest.mark.parametrize("quad", [1, 2])
+def test_every_frame_writes_every_pixel_with_four_samples(hip, oracle_backend, textures, quad):
+    """The same check as for one sample per pixel: a pattern in the frame buffer before every render, so
+    that a tile missing from the list (static classes, cost bins, kept list) cannot hide behind an old
+    frame.  Pooled sample paths in the plain tiles, samples in turn in the quad-mode quarters."""
+    import torch
+    from raytracing_amd.rtx import Frame
+    w, h = 203, 131
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_SPP, 4), (OPT_QUAD, quad)])
+    want = make_default_context(oracle_backend, textures, sky="map.jpg", options=[(OPT_SPP, 4)]).render(oracle_backend.default_camera(), w, h, 3)
+    cam = hip.default_camera()
+    buf = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.Stream()
+    for _ in range(3):
+        buf.fill_(0x5A)
+        torch.cuda.synchronize()
+        ctx.render_device(cam, Frame(w, h, 3, 0, 1), buf.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy().reshape(h, w, 3), want)
