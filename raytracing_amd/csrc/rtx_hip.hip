@@ -151,9 +151,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const unsigned *__res
 }
 // one workgroup of kCostBins threads: block_hist[g][b] becomes the list position at which workgroup g
 // starts to write its tiles of bin b; head = {entries, first cheap entry, quad-mode tiles, quad-mode bins}
+// cheap_cost: tiles in the bins below this cost's bin count as cheap (k_render takes them in batches); 0 = below
+// the average cost
 __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ block_hist, const unsigned long long *__restrict__ block_sum,
                                                         unsigned n, unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap,
-                                                        unsigned *__restrict__ n_out, unsigned *__restrict__ head) {
+                                                        unsigned cheap_cost, unsigned *__restrict__ n_out, unsigned *__restrict__ head) {
     __shared__ unsigned s_total[kCostBins], s_start[kCostBins];
     const unsigned b = threadIdx.x;
     unsigned at = 0;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ b
         const float even = (float)sum / (float)(wave_slots ? wave_slots : 1u);
         const float share = quad_share * even;
         const unsigned limit = share > (float)min_ticks ? (unsigned)share : min_ticks;
-        const unsigned mean = (unsigned)(sum / (n ? n : 1u));
+        const unsigned mean = cheap_cost ? cheap_cost : (unsigned)(sum / (n ? n : 1u));
         // quad mode for the bins at or above the limit's, as long as that stays within `cap` tiles
         const unsigned limit_bin = costBin(limit);
         unsigned heavy = 0, heavy_bins = 0;
@@ -213,6 +215,34 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const unsigned *__r
             }
         }
     }
+}
+
+// The first frame of a view has no costs to go by: its tiles are put into three classes from bounding
+// boxes alone -- those that can see the mesh, those that can see a mirror or glass sphere, the rest --
+// a longest-job-first schedule (a wave that walks the mesh at every bounce runs for hundreds of
+// microseconds; if it only starts halfway through the dispatch the chip idles waiting for it).  The
+// classes are written as stand-in costs and go through the same k_bin_* launches as measured costs do.
+constexpr int kMaxRects = kMaxSmallPrims + 1;
+constexpr unsigned kClassCost0 = 4096u, kClassCost1 = 1024u, kClassCost2 = 1u;
+constexpr unsigned kClassCheapCost = 512u;  // class 2 counts as cheap
+struct TileRects {
+    int n;
+    float r[kMaxRects][4];  // column min, max, image row min, max
+    int cls[kMaxRects];
+};
+__global__ __launch_bounds__(256) void k_tile_classes(TileRects rects, unsigned n, unsigned tiles_x, int row_first, int row_step,
+                                                      unsigned *__restrict__ cost) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned bx = i % tiles_x, by = i / tiles_x;
+    const float c0 = (float)(bx * 8u), c1 = (float)(bx * 8u + 7u);
+    const float r0 = (float)(row_first + (long long)by * 8 * row_step);
+    const float r1 = (float)(row_first + ((long long)by * 8 + 7) * row_step);
+    int cls = 2;
+    for (int k = 0; k < rects.n; ++k)
+        if (c1 >= rects.r[k][0] - 1 && c0 <= rects.r[k][1] + 1 && r1 >= rects.r[k][2] - 1 && r0 <= rects.r[k][3] + 1 && rects.cls[k] < cls)
+            cls = rects.cls[k];
+    cost[i] = cls == 0 ? kClassCost0 : (cls == 1 ? kClassCost1 : kClassCost2);
 }
 
 // The pixel a lane works on; with several samples per pixel (WIDE build only) the lane traces them
@@ -554,6 +584,39 @@ int upload(const std::vector<T> &v, T **dptr, std::vector<void *> &owned) {
 
 }  // namespace
 
+// Device memory with which a render schedules its tiles.  A context owns one set (hipMalloc, grown to the
+// largest frame seen); the allocation-free entry point carves one out of a static device array.
+struct SchedMem {
+    unsigned *heads = nullptr;     // work-queue heads of k_render, two sets: a launch counts in one and clears the other
+    unsigned *cost = nullptr;      // per tile: what it cost in the last frame (100 MHz ticks), or its class's stand-in cost
+    unsigned *entries = nullptr;   // the tile list built from it: `quarters` x cap entries (the longest tiles as four quarters)
+    unsigned *list_hdr = nullptr;  // {entries in the list, first cheap entry}
+    unsigned *bins = nullptr;      // k_bin_*: per-workgroup histograms, then two words of header
+    unsigned long long *bin_sums = nullptr;
+    size_t cap = 0;                // tiles that cost and entries are sized for
+    bool quarters = true;          // entries has room for every tile as four quarters (quad mode)
+};
+constexpr size_t kHeadWords = 2 * kQueues * kHeadStride, kBinWords = kBinBlocks * kCostBins + 2;
+
+// A view = camera + frame description, compared bit for bit.
+struct ViewKey {
+    bool valid = false;
+    rtx_camera cam{};
+    rtx_frame frame{};
+    bool is(const rtx_camera *c, const rtx_frame *f) const {
+        return valid && memcmp(&cam, c, sizeof cam) == 0 && memcmp(&frame, f, sizeof frame) == 0;
+    }
+    void set(const rtx_camera *c, const rtx_frame *f) { valid = true, cam = *c, frame = *f; }
+};
+// What a SchedMem holds at the moment.
+struct SchedState {
+    bool heads_flip = false;
+    bool have_cost = false;  // `cost` holds the measured costs of a frame: of cost_view
+    ViewKey cost_view;
+    ViewKey by_cost_key;     // `entries` was built from measured costs for this view
+    ViewKey static_key;      // `entries` was built from the tile classes for this view
+};
+
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -592,28 +655,13 @@ struct rtx_ctx {
     std::vector<void *> owned;
     int bvh_depth = 0;
     Counters *d_counters = nullptr;
-    unsigned *d_heads = nullptr;      // work-queue heads of k_render, two sets: a launch counts in one and clears the other
-    bool heads_flip = false;
     int resident_blocks[4] = {0, 0, 0, 0};  // grid size of k_render<STATS, WIDE>, index STATS + 2 * WIDE
     int spp = 1;                            // RTX_OPT_SPP
     bool big_spheres = false;               // more spheres than the LDS staging holds: they sit behind a BVH
-    // launch order of the tiles, cached for the last (camera, frame, tile size) it was built for
-    unsigned *d_order = nullptr;
-    size_t d_order_cap = 0;
-    std::vector<unsigned char> order_key;
-    unsigned order_cheap_from = 0;  // position in d_order from which the tiles see none of the projected boxes
-    // schedule feedback: per-tile cost of the last frame, and the tile list sorted by it
-    int feedback = 1;                  // RTX_OPT_SCHEDULE_FEEDBACK
-    int quad_mode = 1;                 // RTX_OPT_QUAD
-    unsigned *d_cost = nullptr;        // per tile: what it cost in the last frame (100 MHz ticks)
-    unsigned *d_entries = nullptr;     // the tile list built from it, the longest tiles as four quarters; then {entries, first cheap entry}
-    unsigned *d_bins = nullptr;        // k_bin_*: per-workgroup histograms, then two words of header
-    unsigned long long *d_bin_sums = nullptr;
-    size_t sched_cap = 0;
-    bool have_cost = false;            // d_cost holds the costs of a frame: of cost_frame under cost_cam
-    rtx_camera cost_cam{};
-    rtx_frame cost_frame{};
-    std::vector<unsigned char> by_cost_key;  // the (camera, frame) the list was built for
+    int feedback = 1;                       // RTX_OPT_SCHEDULE_FEEDBACK
+    int quad_mode = 1;                      // RTX_OPT_QUAD
+    SchedMem sched;                         // the context's own scheduling memory (grown on demand)
+    SchedState sched_state;
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -707,101 +755,46 @@ bool projectBox(const rtx_camera *cam, int W, int H, const float lo[3], const fl
     return true;
 }
 
-// Launch order of the tiles: those that can see the mesh first, then those that can see a mirror or
-// glass sphere, then the rest -- a longest-job-first schedule from bounding boxes alone.  The frame
-// takes as long as its slowest wave; a wave that walks the mesh at every bounce runs for hundreds of
-// microseconds, and if it only starts halfway through the dispatch the chip idles waiting for it.
-// *cheap_from = the list position from which the tiles see none of the boxes (with the natural order:
-// 0 when there are no boxes at all, the end of the list when the mesh may be anywhere).
-int tileOrder(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, int bt, int blocks_x, int blocks_y,
-              const unsigned **out, unsigned *cheap_from) {
-    *out = nullptr;
-    *cheap_from = 0;
-    const size_t n = (size_t)blocks_x * blocks_y;
-    std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame) + sizeof(int));
-    memcpy(key.data(), cam, sizeof(rtx_camera));
-    memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
-    memcpy(key.data() + sizeof(rtx_camera) + sizeof(rtx_frame), &bt, sizeof(int));
-    if (key == c->order_key && c->d_order) {
-        *out = c->d_order;
-        *cheap_from = c->order_cheap_from;
-        return RTX_OK;
-    }
-    struct Rect {
-        float r[4];
-        int cls;
-    };
-    std::vector<Rect> rects;
+// Screen rectangles of what makes tiles expensive, for k_tile_classes: class 0 = the mesh, class 1 = a
+// mirror or glass sphere.  Returns false when the mesh may be anywhere on screen (a corner of its box is
+// not in front of the image plane): no tile counts as cheap then.
+bool tileRects(const rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, TileRects &rects) {
+    rects.n = 0;
     const DevScene &d = c->dev;
     if (d.n_mesh_tris > 0) {
-        Rect r;
-        r.cls = 0;
-        if (projectBox(cam, f->width, f->height, d.mesh_lo, d.mesh_hi, r.r)) rects.push_back(r);
-        else {  // the mesh may be anywhere on screen: keep the natural order, no tile counts as cheap
-            *cheap_from = (unsigned)n;
-            return RTX_OK;
-        }
+        if (!projectBox(cam, f->width, f->height, d.mesh_lo, d.mesh_hi, rects.r[rects.n])) return false;
+        rects.cls[rects.n++] = 0;
     }
     for (size_t i = 0; i < c->spheres.size() && !c->big_spheres; ++i) {  // (a large set is everywhere: no classes from it)
         const Material &m = c->materials[c->sphere_mat[i]];
         if (m.a2 == 0.0f && m.a3 == 0.0f) continue;
         const float4 sp = c->spheres[i];
         const float lo[3] = {sp.x - sp.w, sp.y - sp.w, sp.z - sp.w}, hi[3] = {sp.x + sp.w, sp.y + sp.w, sp.z + sp.w};
-        Rect r;
-        r.cls = 1;
-        if (projectBox(cam, f->width, f->height, lo, hi, r.r)) rects.push_back(r);
+        if (rects.n < kMaxRects && projectBox(cam, f->width, f->height, lo, hi, rects.r[rects.n])) rects.cls[rects.n++] = 1;
     }
-    if (rects.empty()) return RTX_OK;
-    std::vector<unsigned> order[3];
-    for (int by = 0; by < blocks_y; ++by)
-        for (int bx = 0; bx < blocks_x; ++bx) {
-            const float c0 = (float)(bx * bt), c1 = (float)(bx * bt + bt - 1);
-            const float r0 = (float)(f->row_first + (long long)by * bt * f->row_step);
-            const float r1 = (float)(f->row_first + ((long long)by * bt + bt - 1) * f->row_step);
-            int cls = 2;
-            for (const Rect &r : rects)
-                if (c1 >= r.r[0] - 1 && c0 <= r.r[1] + 1 && r1 >= r.r[2] - 1 && r0 <= r.r[3] + 1 && r.cls < cls) cls = r.cls;
-            order[cls].push_back((unsigned)(by * blocks_x + bx));
-        }
-    std::vector<unsigned> all;
-    all.reserve(n);
-    for (auto &o : order) all.insert(all.end(), o.begin(), o.end());
-    if (n > c->d_order_cap) {
-        (void)hipFree(c->d_order);
-        c->d_order = nullptr, c->d_order_cap = 0;
-        HIP_OR_FAIL(hipMalloc((void **)&c->d_order, n * sizeof(unsigned)));
-        c->d_order_cap = n;
-    }
-    // The table may still be in use by an earlier launch on another stream: wait for the device.
-    HIP_OR_FAIL(hipDeviceSynchronize());
-    HIP_OR_FAIL(hipMemcpy(c->d_order, all.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
-    c->order_key = key;
-    c->order_cheap_from = (unsigned)(order[0].size() + order[1].size());
-    *out = c->d_order;
-    *cheap_from = c->order_cheap_from;
-    return RTX_OK;
+    return true;
 }
 
-// Buffers of the schedule feedback, sized for n tiles: cost per tile and the list built from it.
+// Grows the context's own scheduling memory to n tiles: cost per tile and the list built from it.
 int scheduleBuffers(rtx_ctx *c, size_t n) {
-    if (n <= c->sched_cap) return RTX_OK;
+    SchedMem &m = c->sched;
+    if (n <= m.cap) return RTX_OK;
     HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old buffers
-    (void)hipFree(c->d_cost);
-    (void)hipFree(c->d_entries);
-    c->d_cost = nullptr, c->d_entries = nullptr, c->sched_cap = 0;
-    c->have_cost = false, c->by_cost_key.clear();
-    HIP_OR_FAIL(hipMalloc((void **)&c->d_cost, n * sizeof(unsigned)));
-    HIP_OR_FAIL(hipMalloc((void **)&c->d_entries, (4 * n + 2) * sizeof(unsigned)));
-    HIP_OR_FAIL(hipMemset(c->d_cost, 0, n * sizeof(unsigned)));
-    c->sched_cap = n;
+    (void)hipFree(m.cost);
+    (void)hipFree(m.entries);
+    m.cost = nullptr, m.entries = nullptr, m.cap = 0;
+    c->sched_state.have_cost = false, c->sched_state.by_cost_key.valid = false, c->sched_state.static_key.valid = false;
+    HIP_OR_FAIL(hipMalloc((void **)&m.cost, n * sizeof(unsigned)));
+    HIP_OR_FAIL(hipMalloc((void **)&m.entries, 4 * n * sizeof(unsigned)));
+    HIP_OR_FAIL(hipMemset(m.cost, 0, n * sizeof(unsigned)));
+    m.cap = n;
     return RTX_OK;
 }
 
-// Is `cam` close enough to the camera of the frame whose tile costs are in hand for those costs to say
+// Is `cam` close enough to the camera `o` of the frame whose tile costs are in hand for those costs to say
 // where this frame's expensive tiles are?  (Same projection, the basis turned by a few degrees at
 // most, the origin moved by a few per cent of its distance to the scene.)
-bool nearbyView(const rtx_ctx *c, const rtx_camera *cam) {
-    const rtx_camera &o = c->cost_cam;
+bool nearbyView(const rtx_ctx *c, const rtx_camera &o, const rtx_camera *cam) {
     if (cam->tan_half_fov != o.tan_half_fov || cam->add_origin != o.add_origin) return false;
     for (int k = 0; k < 9; ++k)
         if (!(std::fabs(cam->basis[k] - o.basis[k]) <= 0.05f)) return false;
@@ -817,80 +810,88 @@ bool nearbyView(const rtx_ctx *c, const rtx_camera *cam) {
     return move2 <= 0.05f * 0.05f * (dist2 + size2);
 }
 
-// enqueue one render on `stream`; output rows * width * 3 bytes at d_out.  The queue heads, the
-// counters and the timing events belong to the context: one render of a context at a time.
-int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
+using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
+                              unsigned *, unsigned *, unsigned char *, Counters *);
+const RenderKernel kRenderKernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
+
+// Blocks of every k_render variant that are resident at once (the kernel is a loop over tiles; more
+// blocks would only queue).  Worked out once, in rtx_commit.
+int residentBlocks(rtx_ctx *c) {
+    hipDeviceProp_t prop;
+    HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
+    for (int variant = 0; variant < 4; ++variant) {
+        int per_cu = 0;
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kRenderKernels[variant], kBlock, 0));
+        c->resident_blocks[variant] = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
+    }
+    return RTX_OK;
+}
+
+// Enqueues one render on `stream`; output rows * width * 3 bytes at d_out.  `m` (at least as many tiles as
+// the frame has) and `ss` say where the tile lists live and what they hold; the counters and the timing
+// events belong to the context: one render of a context at a time.  Nothing here allocates or waits.
+int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream, const SchedMem &m,
+                 SchedState &ss, bool feedback) {
     const int rows = rtx_frame_rows(f);
     if (rows == 0) return RTX_OK;
     DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows, c->spp};
     const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
     const long long n_tiles = (long long)tiles_x * tiles_y;
-    if (n_tiles > (long long)kTileMask) return fail(RTX_E_LIMIT, "frame too large for one launch");
+    if (n_tiles > (long long)kTileMask || (size_t)n_tiles > m.cap) return fail(RTX_E_LIMIT, "frame too large for one launch");
     DevScene s = c->dev;
     s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-    const unsigned *order = nullptr;
-    if (int e = scheduleBuffers(c, (size_t)n_tiles)) return e;
-    std::vector<unsigned char> key(sizeof(rtx_camera) + sizeof(rtx_frame));
-    memcpy(key.data(), cam, sizeof(rtx_camera));
-    memcpy(key.data() + sizeof(rtx_camera), f, sizeof(rtx_frame));
     // Longest tiles first.  Every frame records what each of its tiles cost.  A frame of the same frame
-    // description whose camera is the previous frame's or close to it gets its list from those costs
-    // (k_bin_*: three small launches in stream order, about 25 us), and a frame of exactly the same view
-    // as the one the list was built for reuses the list.  Anything else -- the first frame, a cut to
-    // another view -- goes by classes from projected bounding boxes (tileOrder).
-    bool list_now = false;
-    const unsigned *n_entries_dev = nullptr;
-    unsigned *const d_n_entries = c->d_entries + 4 * c->sched_cap;  // [0] entries, [1] where the cheap ones begin
+    // description whose camera is the previous frame's or close to it gets its list from those costs, and
+    // a frame of exactly the view a list was built for reuses the list.  Anything else -- the first
+    // frame, a cut to another view -- goes by classes from projected bounding boxes (k_tile_classes).
+    // Either way the list is built by k_bin_*: three small launches in stream order, about 25 us.
+    enum { kReuse, kFromCosts, kFromClasses, kNatural } how = kNatural;
+    TileRects rects;
     unsigned batch_from = 0;
-    if (c->feedback && key == c->by_cost_key) {
-        order = c->d_entries, n_entries_dev = d_n_entries;
-    } else if (c->feedback && c->have_cost && memcmp(f, &c->cost_frame, sizeof(rtx_frame)) == 0 && nearbyView(c, cam)) {
-        order = c->d_entries, n_entries_dev = d_n_entries;
-        list_now = true;
-    } else if (int e = tileOrder(c, cam, f, 8, tiles_x, tiles_y, &order, &batch_from)) {
-        return e;
-    }
-    // blocks that are resident at once: the kernel is a loop over tiles, more blocks would only queue
+    if (feedback && ss.by_cost_key.is(cam, f)) how = kReuse;
+    else if (feedback && ss.have_cost && ss.cost_view.valid && memcmp(f, &ss.cost_view.frame, sizeof(rtx_frame)) == 0 &&
+             nearbyView(c, ss.cost_view.cam, cam))
+        how = kFromCosts;
+    else if (ss.static_key.is(cam, f)) how = kReuse;
+    else if (!tileRects(c, cam, f, rects)) batch_from = (unsigned)n_tiles;  // natural order, nothing is cheap
+    else if (rects.n > 0) how = kFromClasses;                              // (no boxes at all: natural order, everything is cheap)
+    const unsigned *order = how == kNatural ? nullptr : m.entries;
+    const unsigned *list_hdr = how == kNatural ? nullptr : m.list_hdr;
     // the general build of the kernel only where it is needed: a large sphere set, several samples per pixel
     const bool wide = c->big_spheres || c->spp > 1;
-    using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
-                                  unsigned *, unsigned *, unsigned char *, Counters *);
-    const RenderKernel kernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
-    int &resident = c->resident_blocks[variant];
-    if (resident == 0) {
-        int per_cu = 0;
-        hipDeviceProp_t prop;
-        HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
-        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[variant], kBlock, 0));
-        resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
-    }
+    const int resident = c->resident_blocks[variant];
     const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
-    unsigned *const heads = c->d_heads + (c->heads_flip ? kQueues * kHeadStride : 0u);
-    unsigned *const heads_next = c->d_heads + (c->heads_flip ? 0u : kQueues * kHeadStride);
-    if (list_now) {
+    unsigned *const heads = m.heads + (ss.heads_flip ? kQueues * kHeadStride : 0u);
+    unsigned *const heads_next = m.heads + (ss.heads_flip ? 0u : kQueues * kHeadStride);
+    if (how == kFromCosts || how == kFromClasses) {
+        const bool by_cost = how == kFromCosts;
         // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.2 ms,
-        // never more than an eighth of all), 2 every tile
-        const unsigned cap = c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
+        // never more than an eighth of all), 2 every tile; never on a list made from classes
+        const unsigned cap = !by_cost || !m.quarters || c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
         const unsigned per = (unsigned)((n_tiles + kBinBlocks - 1) / kBinBlocks);
-        unsigned *const d_head = c->d_bins + kBinBlocks * kCostBins;
-        hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, c->d_bin_sums);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, c->d_bins, c->d_bin_sums, (unsigned)n_tiles,
+        unsigned *const d_head = m.bins + kBinBlocks * kCostBins;
+        if (!by_cost)
+            hipLaunchKernelGGL(k_tile_classes, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, rects, (unsigned)n_tiles,
+                               (unsigned)tiles_x, f->row_first, f->row_step, m.cost);
+        hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, m.bin_sums);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, m.bins, m.bin_sums, (unsigned)n_tiles,
                            (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 20000u, cap,
-                           d_n_entries, d_head);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, c->d_cost, (unsigned)n_tiles, per, c->d_bins, d_head,
-                           c->d_entries);
+                           by_cost ? 0u : kClassCheapCost, m.list_hdr, d_head);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, d_head,
+                           m.entries);
         HIP_OR_FAIL(hipGetLastError());
-        c->by_cost_key = key;
+        ss.by_cost_key.valid = ss.static_key.valid = false;
+        (by_cost ? ss.by_cost_key : ss.static_key).set(cam, f);
     }
-    hipLaunchKernelGGL(kernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
-                       order, n_entries_dev, batch_from, heads, heads_next, c->d_cost, d_out, c->d_counters);
+    hipLaunchKernelGGL(kRenderKernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
+                       order, list_hdr, batch_from, heads, heads_next, m.cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
-    c->heads_flip = !c->heads_flip;  // only now: a launch that failed has cleared nothing
-    c->cost_cam = *cam, c->cost_frame = *f, c->have_cost = true;
+    ss.heads_flip = !ss.heads_flip;  // only now: a launch that failed has cleared nothing
+    ss.cost_view.set(cam, f), ss.have_cost = true;
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return RTX_OK;
@@ -916,11 +917,12 @@ int rtx_create(rtx_ctx **out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_heads, 2 * kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
-        (e = hipMemset(c->d_heads, 0, 2 * kQueues * kHeadStride * sizeof(unsigned))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_bins, (kBinBlocks * kCostBins + 2) * sizeof(unsigned))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->d_bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
-        delete c;
+        (e = hipMalloc((void **)&c->sched.heads, kHeadWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(c->sched.heads, 0, kHeadWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->sched.bins, kBinWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->sched.list_hdr, 2 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->sched.bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
+        rtx_destroy(c);
         return failHip(e, "rtx_create");
     }
     *out = c;
@@ -933,12 +935,12 @@ void rtx_destroy(rtx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_heads);
-    (void)hipFree(c->d_bins);
-    (void)hipFree(c->d_bin_sums);
-    (void)hipFree(c->d_order);
-    (void)hipFree(c->d_cost);
-    (void)hipFree(c->d_entries);
+    (void)hipFree(c->sched.heads);
+    (void)hipFree(c->sched.bins);
+    (void)hipFree(c->sched.bin_sums);
+    (void)hipFree(c->sched.list_hdr);
+    (void)hipFree(c->sched.cost);
+    (void)hipFree(c->sched.entries);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -959,12 +961,12 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_QUAD:
             if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD: 0 never, 1 automatic, 2 every tile");
             c->quad_mode = (int)value;
-            c->by_cost_key.clear();  // the entry list is rebuilt with the next frame
+            c->sched_state.by_cost_key.valid = false;  // the entry list is rebuilt with the next frame
             break;
         case RTX_OPT_SPP:
             if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
             c->spp = (int)value;
-            c->have_cost = false, c->by_cost_key.clear();  // what a tile costs changes with it
+            c->sched_state.have_cost = false, c->sched_state.by_cost_key.valid = false;  // what a tile costs changes with it
             break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
@@ -1272,6 +1274,7 @@ int rtx_commit(rtx_ctx *c) {
             r[2] = std::fmin(r[2], is.y - b - ez), r[3] = std::fmax(r[3], is.y + b + ez);
         }
     }
+    if (int e = residentBlocks(c)) return e;
     c->committed = true;
     // host copies are no longer needed
     std::vector<unsigned char>().swap(c->sky);
@@ -1296,7 +1299,8 @@ int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned c
         HIP_OR_FAIL(hipMalloc((void **)&c->d_frame, bytes));
         c->d_frame_bytes = bytes;
     }
-    if (int e = launchRender(c, cam, f, c->d_frame, c->stream)) return e;
+    if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
+    if (int e = launchRender(c, cam, f, c->d_frame, c->stream, c->sched, c->sched_state, c->feedback != 0)) return e;
     if (bytes) HIP_OR_FAIL(hipMemcpyAsync(bgr_out, c->d_frame, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_OR_FAIL(hipStreamSynchronize(c->stream));
     if (stats) return rtx_get_stats(c, stats);
@@ -1307,7 +1311,10 @@ int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, voi
     if (int e = checkFrame(c, cam, f)) return e;
     if (rtx_frame_rows(f) > 0 && !d_bgr_out) return fail(RTX_E_INVALID, "null output buffer");
     if (int e = bind(c)) return e;
-    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream);
+    const int rows = rtx_frame_rows(f);
+    if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
+    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, c->sched,
+                        c->sched_state, c->feedback != 0);
 }
 
 int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {
