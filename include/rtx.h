@@ -190,6 +190,20 @@ int rtx_render(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, unsi
  * returns RTX_E_STATE. */
 int rtx_render_device(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, void *d_bgr_out,
                       void *hip_stream);
+/* rtx_render_device for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * Same arguments, same pixels; the call performs no hipMalloc / hipFree (nor any other allocating
+ * routine): the memory its kernels schedule tiles with (work-queue heads, per-tile classes, the tile
+ * list; 4.1 MiB) is a static device array that every GPU the library runs on holds until the process
+ * ends.  Limits and rules:
+ *   - frames of at most 524 288 tiles of 8x8 pixels (e.g. 7680x4320); larger ones return RTX_E_LIMIT;
+ *   - every call on a GPU, from whatever context, shares that GPU's array: calls that overlap on one GPU
+ *     (two streams, two threads) race -- serialise them;
+ *   - the tile list is made afresh from projected bounding boxes on every call (there is no schedule
+ *     feedback and no quad mode), so a frame costs what the first frame of a view costs.
+ * The context must have been created on its GPU by rtx_create, which looks the array up. */
+int rtx_render_device_noalloc(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, void *d_bgr_out,
+                              void *hip_stream);
 /* Ray counts and kernel time of the most recent render on this context (synchronises). */
 int rtx_get_stats(rtx_ctx *ctx, rtx_stats *stats);
 

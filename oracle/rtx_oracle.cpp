@@ -830,6 +830,10 @@ int rtx_render_device(rtx_ctx *, const rtx_camera *, const rtx_frame *, void *, 
     return fail(RTX_E_STATE, "the CPU oracle has no device path");
 }
 
+int rtx_render_device_noalloc(rtx_ctx *, const rtx_camera *, const rtx_frame *, void *, void *) {
+    return fail(RTX_E_STATE, "the CPU oracle has no device path");
+}
+
 int rtx_deinterleave_rows_device(rtx_ctx *, const void *, int, int, int, int, void *, void *) {
     return fail(RTX_E_STATE, "the CPU oracle has no device path");
 }

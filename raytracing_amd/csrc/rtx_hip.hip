@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -617,6 +618,40 @@ struct SchedState {
     ViewKey static_key;      // `entries` was built from the tile classes for this view
 };
 
+// ---------------------------------------------------------------------------------------------
+// Scheduling memory for callers that must not allocate (rtx_render_device_noalloc): one static device
+// array per GPU instead of the context's hipMalloc'ed buffers.  The array's name is only a host-side
+// handle; its address on a device comes from hipGetSymbolAddress (scratchOnDevice, called by rtx_create
+// with that device current) and is what every kernel argument and memset below uses.
+// Layout (byte offsets, each a multiple of 256): queue heads, histogram bins, bin sums, list header,
+// cost per tile, tile list.  No quarters: a list made from tile classes never uses quad mode.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kScratchTiles = 1u << 19;  // 524 288 tiles of 8x8 pixels, e.g. a 7680x4320 frame (518 400)
+constexpr size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+constexpr size_t kScratchHeads = 0;
+constexpr size_t kScratchBins = kScratchHeads + align256(kHeadWords * sizeof(unsigned));
+constexpr size_t kScratchBinSums = kScratchBins + align256(kBinWords * sizeof(unsigned));
+constexpr size_t kScratchListHdr = kScratchBinSums + align256(kBinBlocks * sizeof(unsigned long long));
+constexpr size_t kScratchCost = kScratchListHdr + 256;
+constexpr size_t kScratchEntries = kScratchCost + kScratchTiles * sizeof(unsigned);
+constexpr size_t kScratchBytes = kScratchEntries + kScratchTiles * sizeof(unsigned);  // 4.08 MiB
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, once looked up
+
+// Looks up this GPU's copy of `scratch`; the device must be current.
+static int scratchOnDevice(int device) {
+    if (device < 0 || device >= kMaxDevices) return RTX_OK;  // such a device simply has no allocation-free path
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RTX_OK;
+    void *p = nullptr;
+    HIP_OR_FAIL(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = p;
+    return RTX_OK;
+}
+
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -924,6 +959,10 @@ int rtx_create(rtx_ctx **out, int device_id) {
         (e = hipMalloc((void **)&c->sched.bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
         rtx_destroy(c);
         return failHip(e, "rtx_create");
+    }
+    if (int rc = scratchOnDevice(device_id)) {
+        rtx_destroy(c);
+        return rc;
     }
     *out = c;
     return RTX_OK;
@@ -1315,6 +1354,37 @@ int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, voi
     if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
     return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, c->sched,
                         c->sched_state, c->feedback != 0);
+}
+
+int rtx_render_device_noalloc(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, void *d_bgr_out, void *hip_stream) {
+    if (int e = checkFrame(c, cam, f)) return e;
+    const int rows = rtx_frame_rows(f);
+    if (rows > 0 && !d_bgr_out) return fail(RTX_E_INVALID, "null output buffer");
+    const size_t n_tiles = (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8);
+    if (n_tiles > kScratchTiles) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "rtx_render_device_noalloc: the frame has %zu tiles of 8x8 pixels, the static scheduling memory holds %zu "
+                                  "(e.g. 7680x4320); use rtx_render_device", n_tiles, kScratchTiles);
+        return fail(RTX_E_LIMIT, msg);
+    }
+    unsigned char *const base = c->device < kMaxDevices ? static_cast<unsigned char *>(g_scratch_ptr[c->device]) : nullptr;
+    if (!base) return fail(RTX_E_STATE, "rtx_render_device_noalloc: no static scheduling memory on this device");
+    if (int e = bind(c)) return e;
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    SchedMem m;
+    m.heads = reinterpret_cast<unsigned *>(base + kScratchHeads);
+    m.bins = reinterpret_cast<unsigned *>(base + kScratchBins);
+    m.bin_sums = reinterpret_cast<unsigned long long *>(base + kScratchBinSums);
+    m.list_hdr = reinterpret_cast<unsigned *>(base + kScratchListHdr);
+    m.cost = reinterpret_cast<unsigned *>(base + kScratchCost);
+    m.entries = reinterpret_cast<unsigned *>(base + kScratchEntries);
+    m.cap = kScratchTiles, m.quarters = false;
+    // The array keeps what the last call on this GPU (of any context) left in it.  The queue heads must
+    // start at zero; bins, sums, header, costs and list are written before they are read by this call's
+    // own launches (k_tile_classes, k_bin_*) -- the tile list is always made afresh from the tile classes.
+    HIP_OR_FAIL(hipMemsetAsync(m.heads, 0, kHeadWords * sizeof(unsigned), stream));
+    SchedState fresh;
+    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream, m, fresh, false);
 }
 
 int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {

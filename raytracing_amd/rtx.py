@@ -52,7 +52,7 @@ class Stats(C.Structure):
 # every symbol include/rtx.h and include/rt_host.h declare; the test suite checks the libraries export them all
 RTX_SYMBOLS = ["rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_option", "rtx_set_materials", "rtx_set_lights",
                "rtx_set_spheres", "rtx_set_boxes", "rtx_set_triangles", "rtx_set_mesh", "rtx_set_islands", "rtx_set_water",
-               "rtx_set_envmap", "rtx_commit", "rtx_render", "rtx_render_device", "rtx_get_stats", "rtx_frame_rows",
+               "rtx_set_envmap", "rtx_commit", "rtx_render", "rtx_render_device", "rtx_render_device_noalloc", "rtx_get_stats", "rtx_frame_rows",
                "rtx_deinterleave_rows_device", "rtx_trace_rays", "rtx_intersect_rays"]
 HOST_SYMBOLS = ["rt_default_materials", "rt_material_index", "rt_default_camera", "rt_load_model", "rt_free",
                 "rt_decode_jpeg", "rt_scene_load_default", "rt_scene_load_default_tex", "rt_save_bmp", "rt_main",
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "rtx_commit": (_i, [_vp]),
     "rtx_render": (_i, [_vp, C.POINTER(Camera), C.POINTER(Frame), _vp, C.POINTER(Stats)]),
     "rtx_render_device": (_i, [_vp, C.POINTER(Camera), C.POINTER(Frame), _vp, _vp]),
+    "rtx_render_device_noalloc": (_i, [_vp, C.POINTER(Camera), C.POINTER(Frame), _vp, _vp]),
     "rtx_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "rtx_frame_rows": (_i, [C.POINTER(Frame)]),
     "rtx_deinterleave_rows_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -273,6 +274,10 @@ class Context:
 
     def render_device(self, cam, frame, device_ptr, stream_ptr=None):
         self._ck(self.lib.rtx_render_device(self.handle, C.byref(cam), C.byref(frame), _vp(device_ptr), _vp(stream_ptr or 0)))
+
+    def render_device_noalloc(self, cam, frame, device_ptr, stream_ptr=None):
+        """rtx_render_device without any device allocation inside the call (static scheduling memory)."""
+        self._ck(self.lib.rtx_render_device_noalloc(self.handle, C.byref(cam), C.byref(frame), _vp(device_ptr), _vp(stream_ptr or 0)))
 
     def deinterleave_device(self, gathered_ptr, n_ranks, rows_per_rank, width, height, frame_ptr, stream_ptr=None):
         self._ck(self.lib.rtx_deinterleave_rows_device(self.handle, _vp(gathered_ptr), n_ranks, rows_per_rank, width,
