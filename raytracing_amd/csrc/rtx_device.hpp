@@ -21,7 +21,6 @@ constexpr float kEps = 1.1920928955078125e-07f;   // std::numeric_limits<float>:
 constexpr float kFltMax = 3.4028234663852886e+38f;
 constexpr float kFltMin = 1.1754943508222875e-38f;  // numeric_limits<float>::min()
 constexpr int kMaxDepth = 8;                        // RTX_MAX_DEPTH
-constexpr int kBvhStack = 48;                       // LBVH depth bound: 30 Morton bits + tie-break levels
 
 struct V3 {
     float x, y, z;
@@ -175,6 +174,7 @@ struct Counters {
 struct Hit {
     V3 point, N;
     Material m;
+    int mat_index;  // m = materials[mat_index], diffuse overridden by the water texture / island pattern
 };
 
 // ---------------------------------------------------------------------------------------------

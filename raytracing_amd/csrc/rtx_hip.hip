@@ -5,9 +5,11 @@
 // rtx_device.hpp).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -491,6 +493,8 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     flushCounters<STATS>(lc, counters);
 }
 
+#include "rtx_wavefront.hpp"
+
 template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *__restrict__ orig,
                                                        const float *__restrict__ dir, int n, int depth,
@@ -652,6 +656,27 @@ static int scratchOnDevice(int device) {
     return RTX_OK;
 }
 
+// Sub-list capacities of the pipeline's lists for strips of `strip` samples at recursion depth D, for the worst
+// case of every call hitting and spawning both children (see WfList).  Returns the bytes of all arrays.
+struct WfPlan {
+    unsigned node_cap[kWfLevels + 1] = {}, shadow_cap[kWfLevels + 1] = {}, req_cap[kWfLevels + 1] = {};  // per sub-list
+    size_t bytes = 0;
+    bool fits = true;  // node indices fit the shadow queue's 27 bits, request indices the links' 28
+};
+// Device memory of the level-by-level pipeline (rtx_wavefront.hpp): one block, carved into the per-level
+// request and record arrays for strips of `strip_samples` samples at recursion depth `depth`.
+struct WfMem {
+    void *block = nullptr;
+    size_t block_bytes = 0;
+    size_t strip_samples = 0;
+    int depth = -1, n_lights = 0;
+    WfPlan plan;
+    WfCounters *counters = nullptr;
+    float4 *ray_o[kWfLevels + 1] = {}, *ray_d[kWfLevels + 1] = {}, *thin[kWfLevels + 1] = {};
+    float4 *fat = nullptr, *samples = nullptr;
+    unsigned *shadow_q = nullptr;
+};
+
 struct rtx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -697,6 +722,12 @@ struct rtx_ctx {
     int quad_mode = 1;                      // RTX_OPT_QUAD
     SchedMem sched;                         // the context's own scheduling memory (grown on demand)
     SchedState sched_state;
+    int pipeline = 0;                       // RTX_OPT_PIPELINE
+    WfMem wf;
+    int wf_stack_entries = kStackDepth;     // LDS traversal stack entries per lane of the pipeline's kernels
+    int sphere_bvh_depth = 0;
+    int wf_blocks[3][4] = {};               // resident blocks of k_wf_trace / k_wf_shadow [STATS + 2 * WIDE], k_wf_shade [STATS]
+    size_t wf_budget = (size_t)16 << 30;    // bytes the pipeline's arrays may take
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
 };
@@ -932,6 +963,202 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     return RTX_OK;
 }
 
+// ---- the level-by-level pipeline (rtx_wavefront.hpp) ----
+using WfTraceKernel = void (*)(DevScene, DevCamera, DevFrame, WfStrip, WfArgs, Counters *);
+using WfShadowKernel = void (*)(DevScene, WfArgs, Counters *);
+using WfShadeKernel = void (*)(DevScene, DevFrame, WfArgs, Counters *);
+const WfTraceKernel kWfTrace[4] = {k_wf_trace<false, false>, k_wf_trace<true, false>, k_wf_trace<false, true>, k_wf_trace<true, true>};
+const WfShadowKernel kWfShadow[4] = {k_wf_shadow<false, false>, k_wf_shadow<true, false>, k_wf_shadow<false, true>, k_wf_shadow<true, true>};
+const WfShadeKernel kWfShade[2] = {k_wf_shade<false>, k_wf_shade<true>};
+
+int wavefrontBlocks(rtx_ctx *c) {
+    hipDeviceProp_t prop;
+    HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    // traversal stacks as deep as the scene's trees need (one entry more: the walk stores before it counts)
+    c->wf_stack_entries = std::max(1, std::min(kStackDepth, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
+    const size_t lds = (size_t)c->wf_stack_entries * kBlock * sizeof(int);
+    for (int v = 0; v < 4; ++v) {
+        int per_cu = 0;
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWfTrace[v], kBlock, lds));
+        c->wf_blocks[0][v] = (per_cu > 0 ? per_cu : 1) * cus;
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWfShadow[v], kBlock, lds));
+        c->wf_blocks[1][v] = (per_cu > 0 ? per_cu : 1) * cus;
+    }
+    for (int v = 0; v < 2; ++v) {
+        int per_cu = 0;
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWfShade[v], kBlock, 0));
+        c->wf_blocks[2][v] = (per_cu > 0 ? per_cu : 1) * cus;
+    }
+    return RTX_OK;
+}
+
+WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
+    WfPlan p;
+    const size_t nl = (size_t)(n_lights > 0 ? n_lights : 1);
+    size_t bytes = sizeof(WfCounters) + 256 + strip * sizeof(float4);  // counters, sample colours
+    size_t req_chunks = (strip + kWfChunk - 1) / kWfChunk, fat_entries = 0;  // chunks of the level's requests
+    for (int l = 0; l < D; ++l) {
+        const size_t node_cap = (req_chunks / kWfSub + 1) * kWfChunk;  // chunks c with c % kWfSub == k, 64 nodes each
+        const size_t node_chunks = (size_t)kWfSub * (node_cap / kWfChunk);
+        const size_t req_cap = (node_chunks / kWfSub + 1) * kWfChunk * 2;  // two children per node
+        p.node_cap[l] = (unsigned)node_cap, p.shadow_cap[l] = (unsigned)(node_cap * nl);
+        if (kWfSub * node_cap >= ((size_t)1 << 27) || kWfSub * node_cap * nl >= 0xffffffffull) p.fits = false;
+        fat_entries = std::max(fat_entries, kWfSub * node_cap);
+        if (l + 1 < D) {
+            p.req_cap[l + 1] = (unsigned)req_cap;
+            if (kWfSub * req_cap >= (size_t)kWfMaxIndex) p.fits = false;
+            // requests (the two classes of a sub-list share its region), thin records
+            bytes += kWfSub * req_cap * 2 * sizeof(float4) + kWfSub * node_cap * 3 * sizeof(float4) + 1024;
+            req_chunks = (size_t)kWfSub * (req_cap / kWfChunk) + kWfMaxLists;  // all entries in whole chunks + a partly filled one per sub-list
+        }
+    }
+    if (strip >= (size_t)kWfMaxIndex) p.fits = false;
+    bytes += fat_entries * (4 * sizeof(float4) + nl * sizeof(unsigned)) + 1024;  // fat records, shadow lists
+    p.bytes = bytes;
+    return p;
+}
+
+// Sizes the pipeline's arrays for this frame: whole frame in one strip if that fits the budget.
+int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
+    WfMem &w = c->wf;
+    const int nl = c->dev.n_lights;
+    const size_t unit = (size_t)64 * spp;  // samples of one tile
+    size_t strip = (frame_samples + unit - 1) / unit * unit;
+    WfPlan plan = wavefrontPlan(D, nl, strip);
+    while ((plan.bytes > c->wf_budget || !plan.fits) && strip > unit) {  // halve until it fits
+        strip = std::max(unit, strip / 2 / unit * unit);
+        plan = wavefrontPlan(D, nl, strip);
+    }
+    if (w.block && w.depth == D && w.n_lights == nl && w.strip_samples == strip) return RTX_OK;
+    HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old block
+    (void)hipFree(w.block);
+    w = WfMem();
+    HIP_OR_FAIL(hipMalloc(&w.block, plan.bytes + 256 * (4 * kWfLevels + 8)));
+    w.block_bytes = plan.bytes + 256 * (4 * kWfLevels + 8), w.strip_samples = strip, w.depth = D, w.n_lights = nl;
+    w.plan = plan;
+    unsigned char *p = static_cast<unsigned char *>(w.block);
+    auto take = [&](size_t n) {
+        unsigned char *q = p;
+        p += (n + 255) / 256 * 256;
+        return q;
+    };
+    w.counters = reinterpret_cast<WfCounters *>(take(sizeof(WfCounters)));
+    w.samples = reinterpret_cast<float4 *>(take(strip * sizeof(float4)));
+    size_t fat_entries = 0;
+    for (int l = 0; l < D; ++l) {
+        fat_entries = std::max(fat_entries, (size_t)kWfSub * plan.node_cap[l]);
+        if (l + 1 < D) {
+            w.ray_o[l + 1] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.req_cap[l + 1] * sizeof(float4)));
+            w.ray_d[l + 1] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.req_cap[l + 1] * sizeof(float4)));
+            w.thin[l] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.node_cap[l] * 3 * sizeof(float4)));
+        }
+    }
+    if (D > 0) {
+        w.fat = reinterpret_cast<float4 *>(take(fat_entries * 4 * sizeof(float4)));
+        w.shadow_q = reinterpret_cast<unsigned *>(take(fat_entries * (size_t)(nl > 0 ? nl : 1) * sizeof(unsigned)));
+    }
+    if ((size_t)(p - static_cast<unsigned char *>(w.block)) > w.block_bytes) return fail(RTX_E_NOMEM, "wavefront arrays overrun their block");
+    return RTX_OK;
+}
+
+WfArgs wfArgs(const WfMem &w, int l, int launch) {
+    WfArgs a;
+    a.req = WfList{w.counters->n[0][l], w.plan.req_cap[l], 2 * kWfSub};
+    a.nodes = WfList{w.counters->n[1][l], w.plan.node_cap[l], kWfSub};
+    a.shadows = WfList{w.counters->n[2][l], w.plan.shadow_cap[l], 2 * kWfSub};
+    a.next_req = WfList{w.counters->n[0][l + 1], w.plan.req_cap[l + 1], 2 * kWfSub};
+    a.work = w.counters->work[launch][l];
+    a.ray_o = w.ray_o[l], a.ray_d = w.ray_d[l], a.next_o = w.ray_o[l + 1], a.next_d = w.ray_d[l + 1];
+    a.fat = w.fat, a.shadow_q = w.shadow_q, a.thin = w.thin[l], a.parent = l == 0 ? w.samples : w.thin[l - 1];
+    a.level = l;
+    return a;
+}
+
+// Enqueues one render through the level-by-level pipeline.
+int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
+    const int rows = rtx_frame_rows(f);
+    if (rows == 0) return RTX_OK;
+    if (c->dev.n_lights > kWfMaxLights) return fail(RTX_E_LIMIT, "RTX_OPT_PIPELINE = 1 handles at most 32 lights");
+    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows, c->spp};
+    const unsigned tiles_x = (unsigned)(f->width + 7) / 8, tiles_y = (unsigned)(rows + 7) / 8;
+    const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
+    if (n_tiles > 0xffffffffull / (64u * (unsigned)c->spp)) return fail(RTX_E_LIMIT, "frame too large");
+    const int D = f->depth;
+    if (int e = wavefrontBuffers(c, D, (size_t)n_tiles * 64 * c->spp, c->spp)) return e;
+    const WfMem &w = c->wf;
+    DevScene s = c->dev;
+    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    const DevCamera dcam = devCamera(cam);
+    const bool wide = c->big_spheres || c->spp > 1;
+    const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
+    HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
+    if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
+    const unsigned strip_tiles = (unsigned)(w.strip_samples / (64u * (unsigned)c->spp));
+    for (unsigned long long first = 0; first < n_tiles; first += strip_tiles) {
+        WfStrip strip{(unsigned)first, (unsigned)std::min<unsigned long long>(strip_tiles, n_tiles - first), tiles_x};
+        const unsigned long long samples = (unsigned long long)strip.n_tiles * 64u * (unsigned)c->spp;
+        auto grid = [&](int resident, unsigned long long items) {
+            const unsigned long long chunks = (items + kBlock - 1) / kBlock + kWfMaxLists;
+            return dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(chunks, (unsigned long long)resident)));
+        };
+        const size_t lds = (size_t)c->wf_stack_entries * kBlock * sizeof(int);
+        // RTX_WF_TIMING=1: an event after every launch, the elapsed times printed when the frame is done (diagnostics)
+        static const bool timing = getenv("RTX_WF_TIMING") != nullptr;
+        std::vector<std::pair<const char *, hipEvent_t>> marks;
+        static const bool marks_only = getenv("RTX_WF_MARKS") != nullptr;
+        auto mark = [&](const char *what) {
+            if (marks_only) {
+                (void)hipEventRecord(c->ev1, stream);
+                return;
+            }
+            if (!timing) return;
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            (void)hipEventRecord(e, stream);
+            marks.emplace_back(what, e);
+        };
+        mark("pre");
+        hipLaunchKernelGGL(k_wf_clear, dim3(4), dim3(kBlock), 0, stream, w.counters, std::min(D, kWfLevels));
+        mark("clear");
+        for (int l = 0; l < (D > 0 ? D : 1); ++l) {
+            hipLaunchKernelGGL(kWfTrace[variant], grid(c->wf_blocks[0][variant], samples << l), dim3(kBlock), lds, stream, s, dcam, fr, strip,
+                               wfArgs(w, l, 0), c->d_counters);
+            mark("trace");
+            if (D == 0) break;
+            hipLaunchKernelGGL(kWfShadow[variant], grid(c->wf_blocks[1][variant], (samples << l) * (unsigned)std::max(1, s.n_lights)), dim3(kBlock), lds,
+                               stream, s, wfArgs(w, l, 1), c->d_counters);
+            mark("shadow");
+            hipLaunchKernelGGL(kWfShade[c->stats ? 1 : 0], grid(c->wf_blocks[2][c->stats ? 1 : 0], samples << l), dim3(kBlock), 0, stream, s, fr,
+                               wfArgs(w, l, 2), c->d_counters);
+            mark("shade");
+        }
+        for (int l = D - 2; l >= 0; --l) {
+            hipLaunchKernelGGL(k_wf_resolve, grid(c->wf_blocks[2][0] * 2, samples << l), dim3(kBlock), 0, stream, wfArgs(w, l, 3));
+            mark("resolve");
+        }
+        hipLaunchKernelGGL(k_wf_pixels, grid(c->wf_blocks[2][0] * 2, (unsigned long long)strip.n_tiles * 64u), dim3(kBlock), 0, stream, fr, strip,
+                           w.samples, d_out);
+        HIP_OR_FAIL(hipGetLastError());
+        mark("pixels");
+        if (timing) {
+            (void)hipStreamSynchronize(stream);
+            float whole = 0;
+            (void)hipEventElapsedTime(&whole, c->ev0, marks.back().second);
+            fprintf(stderr, "  ev0 -> last mark %8.1f us\n", whole * 1e3f);
+            for (size_t k = 1; k < marks.size(); ++k) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, marks[k - 1].second, marks[k].second);
+                fprintf(stderr, "  %-8s %8.1f us\n", marks[k].first, ms * 1e3f);
+            }
+            for (auto &m : marks) (void)hipEventDestroy(m.second);
+        }
+    }
+    HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return RTX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -980,6 +1207,7 @@ void rtx_destroy(rtx_ctx *c) {
     (void)hipFree(c->sched.list_hdr);
     (void)hipFree(c->sched.cost);
     (void)hipFree(c->sched.entries);
+    (void)hipFree(c->wf.block);
     (void)hipFree(c->d_frame);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1006,6 +1234,14 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
             c->spp = (int)value;
             c->sched_state.have_cost = false, c->sched_state.by_cost_key.valid = false;  // what a tile costs changes with it
+            break;
+        case RTX_OPT_PIPELINE:
+            if (value > 1) return fail(RTX_E_INVALID, "RTX_OPT_PIPELINE: 0 one kernel per frame, 1 level by level");
+            c->pipeline = (int)value;
+            break;
+        case RTX_OPT_PIPELINE_BUDGET_MB:
+            if (value == 0) return fail(RTX_E_INVALID, "RTX_OPT_PIPELINE_BUDGET_MB: at least 1");
+            c->wf_budget = (size_t)value << 20;
             break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
@@ -1214,6 +1450,7 @@ int rtx_commit(rtx_ctx *c) {
         SahBuilder builder(boxes);
         const int depth = builder.build(nodes, kStackDepth);
         if (depth > kStackDepth) return fail(RTX_E_LIMIT, "sphere BVH deeper than the traversal stack");
+        c->sphere_bvh_depth = depth;
         BvhNode *dn;
         if (int e = upload(nodes, &dn, c->owned)) return e;
         d.sphere_bvh = dn;
@@ -1314,6 +1551,7 @@ int rtx_commit(rtx_ctx *c) {
         }
     }
     if (int e = residentBlocks(c)) return e;
+    if (int e = wavefrontBlocks(c)) return e;
     c->committed = true;
     // host copies are no longer needed
     std::vector<unsigned char>().swap(c->sky);
@@ -1338,8 +1576,12 @@ int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned c
         HIP_OR_FAIL(hipMalloc((void **)&c->d_frame, bytes));
         c->d_frame_bytes = bytes;
     }
-    if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
-    if (int e = launchRender(c, cam, f, c->d_frame, c->stream, c->sched, c->sched_state, c->feedback != 0)) return e;
+    if (c->pipeline == 1) {
+        if (int e = launchWavefront(c, cam, f, c->d_frame, c->stream)) return e;
+    } else {
+        if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
+        if (int e = launchRender(c, cam, f, c->d_frame, c->stream, c->sched, c->sched_state, c->feedback != 0)) return e;
+    }
     if (bytes) HIP_OR_FAIL(hipMemcpyAsync(bgr_out, c->d_frame, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_OR_FAIL(hipStreamSynchronize(c->stream));
     if (stats) return rtx_get_stats(c, stats);
@@ -1351,9 +1593,10 @@ int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, voi
     if (rtx_frame_rows(f) > 0 && !d_bgr_out) return fail(RTX_E_INVALID, "null output buffer");
     if (int e = bind(c)) return e;
     const int rows = rtx_frame_rows(f);
+    hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    if (c->pipeline == 1) return launchWavefront(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream);
     if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
-    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream, c->sched,
-                        c->sched_state, c->feedback != 0);
+    return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream, c->sched, c->sched_state, c->feedback != 0);
 }
 
 int rtx_render_device_noalloc(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, void *d_bgr_out, void *hip_stream) {

@@ -457,6 +457,7 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
         mat = s.island_mat;
     }
     h.m = q.materials[mat];
+    h.mat_index = mat;
     if (kind == 5) {
         // texture tiles every `scale` units, nearest texel, blend (tex*0.3 + diffuse)/2: src/Scene.cpp:46-51
         float x = h.point.x / s.water_scale, z = h.point.z / s.water_scale;
