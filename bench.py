@@ -346,7 +346,7 @@ def main():
         # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
         roofline = {
-            "bound": "valu", "kernel": "k_render<false, true>" if stress else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "bound": "valu", "kernel": "k_wf_trace + k_wf_shadow + k_wf_shade<.., true> (level-by-level pipeline, all launches of a frame)" if stress else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "

@@ -124,12 +124,14 @@ enum rtx_option {
                                  dx = {.125, -.375, .375, -.125}, dy = {.375, .125, -.125, -.375} (a
                                  rotated grid); the pixel is (((c0 + c1) + c2) + c3) * 0.25 in
                                  binary32, then clamped and truncated to bytes as with one sample   */
-    RTX_OPT_PIPELINE = 10,    /* 0 (default): one kernel per frame, a lane follows its pixel's whole call tree
+    RTX_OPT_PIPELINE = 10,    /* 0: one kernel per frame, a lane follows its pixel's whole call tree
                                  (Scene::traceRay's recursion as a per-lane stack); 1: the frame is traced
                                  level by level of that tree -- closest-hit rays, shadow rays and shading
                                  of one recursion depth each in a launch of their own over compacted ray
-                                 lists, colours summed bottom-up in the reference's order.  Same pixels,
-                                 same ray counts; no schedule feedback, no quad mode                 */
+                                 lists, colours summed bottom-up in the reference's order; 2 (default):
+                                 whichever measured faster for the kind of scene (level by level when
+                                 the spheres sit behind a BVH, one kernel otherwise).  Same pixels, same
+                                 ray counts; level by level has no schedule feedback and no quad mode */
     RTX_OPT_PIPELINE_BUDGET_MB = 11, /* MiB of device memory the arrays of RTX_OPT_PIPELINE = 1 may take (default
                                  16384); a frame that needs more is traced in strips of tiles      */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only

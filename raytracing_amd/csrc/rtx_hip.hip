@@ -722,7 +722,7 @@ struct rtx_ctx {
     int quad_mode = 1;                      // RTX_OPT_QUAD
     SchedMem sched;                         // the context's own scheduling memory (grown on demand)
     SchedState sched_state;
-    int pipeline = 0;                       // RTX_OPT_PIPELINE
+    int pipeline = 2;                       // RTX_OPT_PIPELINE
     WfMem wf;
     int wf_stack_entries = kStackDepth;     // LDS traversal stack entries per lane of the pipeline's kernels
     int sphere_bvh_depth = 0;
@@ -1075,6 +1075,12 @@ WfArgs wfArgs(const WfMem &w, int l, int launch) {
     return a;
 }
 
+// Which pipeline renders this context's frames (RTX_OPT_PIPELINE).  Left to itself the library goes level by
+// level when the spheres sit behind a BVH -- measured on the 10 000-sphere scene: 122 ms against 177 ms for a
+// 4096 x 4096 frame with 4 samples per pixel -- and uses the one-kernel pipeline otherwise (0.92 ms against
+// 2.0 ms for the default scene at 3840 x 2160).
+bool byLevels(const rtx_ctx *c) { return c->pipeline == 1 || (c->pipeline == 2 && c->big_spheres && c->dev.n_lights <= kWfMaxLights); }
+
 // Enqueues one render through the level-by-level pipeline.
 int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned char *d_out, hipStream_t stream) {
     const int rows = rtx_frame_rows(f);
@@ -1236,7 +1242,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             c->sched_state.have_cost = false, c->sched_state.by_cost_key.valid = false;  // what a tile costs changes with it
             break;
         case RTX_OPT_PIPELINE:
-            if (value > 1) return fail(RTX_E_INVALID, "RTX_OPT_PIPELINE: 0 one kernel per frame, 1 level by level");
+            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_PIPELINE: 0 one kernel per frame, 1 level by level, 2 automatic");
             c->pipeline = (int)value;
             break;
         case RTX_OPT_PIPELINE_BUDGET_MB:
@@ -1576,7 +1582,7 @@ int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned c
         HIP_OR_FAIL(hipMalloc((void **)&c->d_frame, bytes));
         c->d_frame_bytes = bytes;
     }
-    if (c->pipeline == 1) {
+    if (byLevels(c)) {
         if (int e = launchWavefront(c, cam, f, c->d_frame, c->stream)) return e;
     } else {
         if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
@@ -1594,7 +1600,7 @@ int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, voi
     if (int e = bind(c)) return e;
     const int rows = rtx_frame_rows(f);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    if (c->pipeline == 1) return launchWavefront(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream);
+    if (byLevels(c)) return launchWavefront(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream);
     if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
     return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream, c->sched, c->sched_state, c->feedback != 0);
 }
