@@ -227,6 +227,27 @@ int rtx_frame_rows(const rtx_frame *frame);
 int rtx_deinterleave_rows_device(rtx_ctx *ctx, const void *d_gathered, int n_ranks, int rows_per_rank,
                                  int width, int height, void *d_frame, void *hip_stream);
 
+/* One frame over several GPUs from one process.  replaces: the OpenMP loop over the rows of the frame and its
+ * thread count (src/Scene.cpp:214-215, `-threads`: src/Scene.cpp:232).  Rank r of the group renders rows
+ * r, r + n, ... on GPU device_ids[r] (a row-interleaved partition: the cheap sky rows and the expensive rows
+ * through the model are spread evenly); the ranks' rows are gathered on device_ids[0] over RCCL (send / recv
+ * pairs straight into the root, point-to-point xGMI) and put in place by a de-interleave kernel.  The scene
+ * is replicated: set it on every rank's context (rtx_group_ctx) with the rtx_set_* calls, then
+ * rtx_group_commit.  A device id may be repeated (several ranks on one GPU, for tests); ranks that share the
+ * root's GPU render straight into the gathered buffer.  librccl is loaded at run time, only for groups that
+ * span more than one GPU.  One host thread drives the group; errors: rtx_group_last_error(). */
+typedef struct rtx_group rtx_group;
+int rtx_group_create(rtx_group **out, const int *device_ids, int n_devices);
+void rtx_group_destroy(rtx_group *group);
+int rtx_group_size(const rtx_group *group);
+rtx_ctx *rtx_group_ctx(rtx_group *group, int rank);
+int rtx_group_commit(rtx_group *group);
+/* bgr_out: host buffer of height * width * 3 bytes; stats (may be NULL): ray counts summed over the ranks,
+ * kernel_ms the slowest rank's. */
+int rtx_group_render(rtx_group *group, const rtx_camera *cam, int width, int height, int depth,
+                     unsigned char *bgr_out, rtx_stats *stats);
+const char *rtx_group_last_error(void);
+
 /* Traces caller-supplied rays through Scene::traceRay semantics (src/Scene.cpp:83-106) and
  * returns float RGB per ray, un-clamped.  Used by the parity tests to probe single rays.
  * orig/dir = n x 3, rgb_out = n x 3 (host memory). */

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -835,6 +836,62 @@ int rtx_render_device(rtx_ctx *, const rtx_camera *, const rtx_frame *, void *, 
 int rtx_render_device_noalloc(rtx_ctx *, const rtx_camera *, const rtx_frame *, void *, void *) {
     return fail(RTX_E_STATE, "the CPU oracle has no device path");
 }
+
+// Groups: the oracle has no devices, so a "device" is just another context; rank r renders rows r, r + n, ...
+// with the same loop and the rows are put back in place on the host.  (Checks the partition arithmetic of
+// the product's rtx_group_render and keeps the host layer's command line usable on this build.)
+struct rtx_group {
+    std::vector<rtx_ctx *> ctx;
+};
+int rtx_group_create(rtx_group **out, const int *device_ids, int n_devices) {
+    if (!out || !device_ids || n_devices <= 0 || n_devices > 64) return fail(RTX_E_INVALID, "rtx_group_create: 1 to 64 ranks");
+    rtx_group *g = new rtx_group();
+    for (int r = 0; r < n_devices; ++r) {
+        rtx_ctx *c = nullptr;
+        if (int e = rtx_create(&c, device_ids[r])) {
+            rtx_group_destroy(g);
+            return e;
+        }
+        g->ctx.push_back(c);
+    }
+    *out = g;
+    return RTX_OK;
+}
+void rtx_group_destroy(rtx_group *g) {
+    if (!g) return;
+    for (rtx_ctx *c : g->ctx) rtx_destroy(c);
+    delete g;
+}
+int rtx_group_size(const rtx_group *g) { return g ? (int)g->ctx.size() : 0; }
+rtx_ctx *rtx_group_ctx(rtx_group *g, int rank) { return g && rank >= 0 && rank < (int)g->ctx.size() ? g->ctx[rank] : nullptr; }
+int rtx_group_commit(rtx_group *g) {
+    if (!g) return fail(RTX_E_INVALID, "null group");
+    for (rtx_ctx *c : g->ctx)
+        if (int e = rtx_commit(c)) return e;
+    return RTX_OK;
+}
+int rtx_group_render(rtx_group *g, const rtx_camera *cam, int width, int height, int depth, unsigned char *bgr_out, rtx_stats *stats) {
+    if (!g || !cam || !bgr_out || width <= 0 || height <= 0) return fail(RTX_E_INVALID, "rtx_group_render: bad arguments");
+    const int G = (int)g->ctx.size();
+    const size_t row_bytes = (size_t)width * 3;
+    if (stats) memset(stats, 0, sizeof *stats);
+    for (int r = 0; r < G; ++r) {
+        const rtx_frame fr = {width, height, depth, r, G};
+        const int rows = rtx_frame_rows(&fr);
+        std::vector<unsigned char> mine((size_t)rows * row_bytes);
+        rtx_stats s;
+        if (int e = rtx_render(g->ctx[r], cam, &fr, mine.data(), &s)) return e;
+        for (int k = 0; k < rows; ++k) memcpy(bgr_out + (size_t)(r + k * G) * row_bytes, mine.data() + (size_t)k * row_bytes, row_bytes);
+        if (stats) {
+            uint64_t *acc = reinterpret_cast<uint64_t *>(stats);
+            const uint64_t *add = reinterpret_cast<const uint64_t *>(&s);
+            for (size_t k = 0; k < offsetof(rtx_stats, kernel_ms) / sizeof(uint64_t); ++k) acc[k] += add[k];
+            stats->kernel_ms += s.kernel_ms;
+        }
+    }
+    return RTX_OK;
+}
+const char *rtx_group_last_error(void) { return rtx_last_error(); }
 
 int rtx_deinterleave_rows_device(rtx_ctx *, const void *, int, int, int, int, void *, void *) {
     return fail(RTX_E_STATE, "the CPU oracle has no device path");

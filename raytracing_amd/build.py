@@ -17,12 +17,18 @@ PKG = os.path.join(ROOT, "raytracing_amd")
 CSRC = os.path.join(PKG, "csrc")
 HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("material.cpp", "scene.cpp", "host_api.cpp", "jpeg_decoder.cpp")]
 HIP_SRC = os.path.join(CSRC, "rtx_hip.hip")
+GROUP_SRC = os.path.join(CSRC, "rtx_group.cpp")
 LIB = os.path.join(PKG, "librtx_hip.so")
+LIB_FAST = os.path.join(PKG, "librtx_hip_fast.so")
 EXE = os.path.join(PKG, "rt")
 
 # -ffp-contract=off: pixel arithmetic must not be fused into FMA (the reference is an SSE2 build)
-HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall",
-            "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+HIPFLAGS = COMMON + ["-ffp-contract=off"]
+# The tolerance build of the same sources (librtx_hip_fast.so): fused multiply-add, hardware-rate division and
+# square root (2.5 ulp instead of correctly rounded), powf on the exp / log units.  Not bit-faithful: within the
+# stated tolerance of the path (PSNR >= 50 dB, >= 99.9 % of pixels within 1/255), which tests/test_gpu_fast_math.py holds it to.
+FASTFLAGS = COMMON + ["-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-DRTX_FAST_MATH=1"]
 
 
 def _newer(target, sources):
@@ -33,7 +39,7 @@ def _newer(target, sources):
 
 
 def _all_sources():
-    out = [HIP_SRC] + HOST_SRC
+    out = [HIP_SRC, GROUP_SRC] + HOST_SRC
     for d in (CSRC, os.path.join(CSRC, "host"), os.path.join(ROOT, "include")):
         out += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".h"))]
     return out
@@ -48,12 +54,17 @@ def hipcc():
 
 def build_hip(force=False, verbose=True):
     srcs = _all_sources()
-    if not force and _newer(LIB, srcs) and _newer(EXE, srcs):
+    if not force and _newer(LIB, srcs) and _newer(EXE, srcs) and _newer(LIB_FAST, srcs):
         return LIB
-    cmd = [hipcc()] + HIPFLAGS + ["-shared", "-Wl,-Bsymbolic", HIP_SRC] + HOST_SRC + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    procs = []
+    for flags, lib in ((HIPFLAGS, LIB), (FASTFLAGS, LIB_FAST)):  # the two builds side by side
+        cmd = [hipcc()] + flags + ["-shared", "-Wl,-Bsymbolic", HIP_SRC, GROUP_SRC] + HOST_SRC + ["-ldl", "-o", lib]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = [hipcc(), "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "host", "rt_main.cpp"),
            "-L" + PKG, "-lrtx_hip", "-Wl,-rpath,$ORIGIN", "-o", EXE]
     if verbose:

@@ -63,6 +63,7 @@ rt::Settings parseArgs(int argc, char **argv) {
         else if (arg == "-envmap") s.envmap = argv[i + 1];
         else if (arg == "-resources") s.resources = argv[i + 1];
         else if (arg == "-device") s.device = atoi(argv[i + 1]);
+        else if (arg == "-gpus") s.gpus = atoi(argv[i + 1]);
     }
     return s;
 }

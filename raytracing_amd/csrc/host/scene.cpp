@@ -165,6 +165,11 @@ int Scene::upload(rtx_ctx *ctx, unsigned mask, const std::string &bunny_path, co
 int Scene::run(const Settings &settings) const {
     using clock = std::chrono::steady_clock;
     const auto t_start = clock::now();
+    // (the reference's frame size is a compile-time constant; here it comes from the command line)
+    if (settings.width <= 0 || settings.height <= 0 || (long long)settings.width * settings.height > (1ll << 30) || settings.depth < 0) {
+        std::cout << "Error: bad frame size or depth (" << settings.width << " x " << settings.height << ", depth " << settings.depth << ")" << std::endl;
+        return -1;
+    }
     const std::string water_path = settings.resources + "/water.jpg";
     const std::string sky_path = settings.envmap.empty() ? settings.resources + "/map2.jpg" : settings.envmap;
     unsigned char *water = nullptr, *sky = nullptr;
@@ -177,7 +182,7 @@ int Scene::run(const Settings &settings) const {
     std::cout << "[Current settings]" << std::endl;
     std::cout << "Output path: " << settings.out << std::endl;
     std::cout << "Scene number: " << settings.scene << std::endl;
-    std::cout << "Threads: " << settings.threads << " (ignored: the pixel loop runs on GPU " << settings.device << ")" << std::endl;
+    std::cout << "Threads: " << settings.threads << " (ignored: the pixel loop runs on " << settings.gpus << " GPU(s) from " << settings.device << ")" << std::endl;
     std::cout << "\nRendering image..." << std::endl;
     if (rt_decode_jpeg(sky_path.c_str(), &sky, &sw, &sh, &sn) != 0 || sn != 3) {
         // the reference prints this and then crashes in the first sky lookup (src/SceneObjects.cpp:424-427, 444)
@@ -185,24 +190,28 @@ int Scene::run(const Settings &settings) const {
         rt_free(water), rt_free(sky);
         return -1;
     }
-    rtx_ctx *ctx = nullptr;
-    int rc = rtx_create(&ctx, settings.device);
-    if (rc == 0) rc = upload(ctx, RT_MASK_ALL, settings.resources + "/bunny.obj", water, ww, wh, sky, sw, sh);
+    // one context per GPU, the same scene on each; one GPU is a group of one
+    std::vector<int> ids;
+    for (int k = 0; k < (settings.gpus > 1 ? settings.gpus : 1); ++k) ids.push_back(settings.device + k);
+    rtx_group *group = nullptr;
+    int rc = rtx_group_create(&group, ids.data(), (int)ids.size());
+    for (int r = 0; rc == 0 && r < (int)ids.size(); ++r)
+        rc = upload(rtx_group_ctx(group, r), RT_MASK_ALL, settings.resources + "/bunny.obj", water, ww, wh, sky, sw, sh);
     rt_free(water), rt_free(sky);
-    if (rc == 0) rc = rtx_commit(ctx);
-    std::vector<unsigned char> image((size_t)settings.width * settings.height * 3);
+    if (rc == 0) rc = rtx_group_commit(group);
+    std::vector<unsigned char> image;
     if (rc == 0) {
+        image.resize((size_t)settings.width * settings.height * 3);
         rtx_camera cam;
         defaultCamera(&cam);
-        rtx_frame fr{settings.width, settings.height, settings.depth, 0, 1};
         const auto t0 = clock::now();
-        rc = rtx_render(ctx, &cam, &fr, image.data(), nullptr);
+        rc = rtx_group_render(group, &cam, settings.width, settings.height, settings.depth, image.data(), nullptr);
         const auto t1 = clock::now();
         if (rc == 0) std::cout << "Done. Render time: " << std::chrono::duration<double>(t1 - t0).count() << std::endl;
     }
-    if (rc != 0) std::cerr << "rtx error: " << rtx_last_error() << std::endl;
+    if (rc != 0) std::cerr << "rtx error: " << (rtx_group_last_error()[0] ? rtx_group_last_error() : rtx_last_error()) << std::endl;
     if (rc == 0) rc = rt_save_bmp(image.data(), settings.width, settings.height, settings.out.c_str());
-    rtx_destroy(ctx);
+    rtx_group_destroy(group);
     std::cout << "Total time (including loading textures and models): "
               << std::chrono::duration<double>(clock::now() - t_start).count() << std::endl;
     return rc == 0 ? 0 : -1;

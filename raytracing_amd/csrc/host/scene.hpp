@@ -19,6 +19,7 @@ struct Settings {  // include/Scene.h:8-15
     std::string resources = "../resources";    // src/Scene.cpp:154,236
     std::string envmap;                        // default: <resources>/map2.jpg, include/SceneObjects.h:142
     int device = 0;
+    int gpus = 1;  // rows of the frame interleaved over GPUs device, device + 1, ... (the reference: OpenMP threads)
 };
 
 struct Spheres {

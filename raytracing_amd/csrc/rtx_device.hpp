@@ -129,7 +129,10 @@ struct DevScene {
 
 // The analytic part of the scene (a few hundred bytes to a few KB) staged in LDS once per block.
 // Every ray of every lane walks these lists; from global memory each list element costs a
-// dependent scalar-load round trip per ray, from LDS a broadcast read.
+// dependent scalar-load round trip per ray, from LDS a broadcast read.  The staging holds the first
+// kMaxMaterials / kMaxLights / kMaxSmallPrims entries of each list; longer lists are legal, their
+// tails are read from global memory (the loops run over the staged part first, then over the tail, so
+// the reference's list order -- which decides ties -- is kept).
 constexpr int kMaxMaterials = 32, kMaxLights = 8, kMaxSmallPrims = 16;
 struct SmallScene {
     Material materials[kMaxMaterials];
@@ -148,19 +151,30 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
     auto copy = [&](void *dst, const void *src, int dwords) {
         for (int i = t; i < dwords; i += n) static_cast<unsigned *>(dst)[i] = static_cast<const unsigned *>(src)[i];
     };
-    copy(q.materials, s.materials, s.n_materials * 9);
-    copy(q.lights, s.lights, s.n_lights * 4);
+    auto staged = [](int n_list, int room) { return n_list < room ? n_list : room; };
+    copy(q.materials, s.materials, staged(s.n_materials, kMaxMaterials) * 9);
+    copy(q.lights, s.lights, staged(s.n_lights, kMaxLights) * 4);
     if (s.n_spheres <= kMaxSmallPrims) {  // larger sets stay in global memory behind their BVH
         copy(q.spheres, s.spheres, s.n_spheres * 4);
         copy(q.sphere_mat, s.sphere_mat, s.n_spheres);
     }
-    copy(q.islands, s.islands, s.n_islands * 4);
-    copy(q.tris, s.tris, s.n_tris * 9);
-    copy(q.tri_mat, s.tri_mat, s.n_tris);
-    copy(q.boxes, s.boxes, s.n_boxes * 6);
-    copy(q.box_mat, s.box_mat, s.n_boxes);
+    copy(q.islands, s.islands, staged(s.n_islands, kMaxSmallPrims) * 4);
+    copy(q.tris, s.tris, staged(s.n_tris, kMaxSmallPrims) * 9);
+    copy(q.tri_mat, s.tri_mat, staged(s.n_tris, kMaxSmallPrims));
+    copy(q.boxes, s.boxes, staged(s.n_boxes, kMaxSmallPrims) * 6);
+    copy(q.box_mat, s.box_mat, staged(s.n_boxes, kMaxSmallPrims));
     copy(&q.math, &kRefMathTables, (int)(sizeof(RefMathTables) / 4));
 }
+
+// List entry i: from the staging while it reaches, from global memory beyond.  Only the general build of the
+// kernels (WIDE) knows about lists longer than the staging; the host launches it when a scene has one.
+template <bool WIDE> __device__ __forceinline__ float4 lightAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxLights ? q.lights[i] : s.lights[i]; }
+template <bool WIDE> __device__ __forceinline__ Material materialAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxMaterials ? q.materials[i] : s.materials[i]; }
+template <bool WIDE> __device__ __forceinline__ float4 islandAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.islands[i] : s.islands[i]; }
+template <bool WIDE> __device__ __forceinline__ const float *triAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.tris + 9 * i : s.tris + 9 * (size_t)i; }
+template <bool WIDE> __device__ __forceinline__ const float *boxAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.boxes + 6 * i : s.boxes + 6 * (size_t)i; }
+template <bool WIDE> __device__ __forceinline__ int triMatAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.tri_mat[i] : s.tri_mat[i]; }
+template <bool WIDE> __device__ __forceinline__ int boxMatAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.box_mat[i] : s.box_mat[i]; }
 
 // Statistics slots, in the order of rtx_stats' 64-bit fields (include/rtx.h).
 enum CounterSlot {

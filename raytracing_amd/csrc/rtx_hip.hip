@@ -271,7 +271,7 @@ __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &
             hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
         }
         V3 c;
-        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
+        if (pathConsume<STATS, WIDE>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
             if constexpr (WIDE) {
                 if (fr.spp > 1) {
                     // RTX_OPT_SPP = 4: (((c0 + c1) + c2) + c3) * 0.25 over the rotated grid of include/rtx.h
@@ -340,7 +340,7 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
                 hit = sceneIntersect<STATS, true>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
             }
             V3 c;
-            if (pathConsume<STATS>(s, q, st, frames, hit, h, md, -1, c, lc)) {
+            if (pathConsume<STATS, true>(s, q, st, frames, hit, h, md, -1, c, lc)) {
                 float *o = samples + 3 * path;  // [sample][pixel][rgb] = 3 * (64 * sample + pixel)
                 o[0] = c.x, o[1] = c.y, o[2] = c.z;
                 active = false;
@@ -526,8 +526,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const flo
     h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
     h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
     float md;
-    const bool ok = sceneIntersect<false, WIDE>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
-                                          v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md,
+    const V3 from = v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]);
+    const bool ok = sceneIntersect<false, WIDE>(s, q, from, v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md,
                                           s_stack + threadIdx.x, kBlock, lc);
     float *o = out16 + 16 * (size_t)i;
     o[0] = ok ? 1.0f : 0.0f;
@@ -718,6 +718,8 @@ struct rtx_ctx {
     int resident_blocks[4] = {0, 0, 0, 0};  // grid size of k_render<STATS, WIDE>, index STATS + 2 * WIDE
     int spp = 1;                            // RTX_OPT_SPP
     bool big_spheres = false;               // more spheres than the LDS staging holds: they sit behind a BVH
+    float bounded_objects[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};  // box around loose triangles, boxes, mesh and islands
+    bool long_lists = false;                // another list is longer than its LDS staging: the general build of the kernels reads its tail from global memory
     int feedback = 1;                       // RTX_OPT_SCHEDULE_FEEDBACK
     int quad_mode = 1;                      // RTX_OPT_QUAD
     SchedMem sched;                         // the context's own scheduling memory (grown on demand)
@@ -876,6 +878,61 @@ bool nearbyView(const rtx_ctx *c, const rtx_camera &o, const rtx_camera *cam) {
     return move2 <= 0.05f * 0.05f * (dist2 + size2);
 }
 
+// The two box filters in front of the sphere loop of a small sphere set (castBegin) must let through every ray
+// that Sphere::rayIntersect can accept.  Its rounding lets a ray pass the centre at up to sqrt(r^2 + k^2 L^2)
+// instead of r, L being the distance from the ray's origin to the sphere and k = kSphereSlack (see sphereWalk):
+// a small sphere far from the origin is "hit" well outside its box.  So the boxes are sized per launch, for the
+// largest L a ray of that launch can have.  Origins are the camera (or the caller's ray origins), points on the
+// bounded objects, and points on the water / island planes, which lie within one far clip of either (a ray
+// that leaves a horizontal plane does not come back to it unless an object sends it).
+void sphereGateBounds(const rtx_ctx *c, DevScene &s, float origin_reach) {
+    if (s.n_spheres <= 0 || s.sphere_bvh) return;
+    const float *m = s.sphere_root_c;
+    float object_reach = 0.0f;  // the farthest point of the bounded objects from the spheres' centre
+    for (int k = 0; k < 8; ++k) {
+        float d2 = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = c->bounded_objects[a], hi = c->bounded_objects[3 + a];
+            if (!(lo <= hi)) continue;
+            const float p = ((k >> a) & 1) ? hi : lo;
+            d2 += (p - m[a]) * (p - m[a]);
+        }
+        object_reach = std::fmax(object_reach, std::sqrt(d2));
+    }
+    const float L = (std::fmax(origin_reach, object_reach) + std::fabs(c->far_clip) + s.sphere_root_h) * 1.01f;
+    float b[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+    for (const float4 &sp : c->spheres) {
+        const float r = std::fabs(sp.w);
+        const float reach = std::sqrt(r * r + kSphereSlack * kSphereSlack * L * L) * 1.001f + 1e-6f;
+        const float p[3] = {sp.x, sp.y, sp.z};
+        for (int a = 0; a < 3; ++a) {
+            const float e = 1e-5f * std::fabs(p[a]);
+            b[a] = std::fmin(b[a], p[a] - reach - e), b[3 + a] = std::fmax(b[3 + a], p[a] + reach + e);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        s.sphere_bounds[a] = b[a], s.sphere_bounds[3 + a] = b[3 + a];
+        s.object_bounds[a] = std::fmin(b[a], c->bounded_objects[a]), s.object_bounds[3 + a] = std::fmax(b[3 + a], c->bounded_objects[3 + a]);
+    }
+}
+float distanceToSpheres(const rtx_ctx *c, const float o[3]) {
+    const float *m = c->dev.sphere_root_c;
+    return std::sqrt((o[0] - m[0]) * (o[0] - m[0]) + (o[1] - m[1]) * (o[1] - m[1]) + (o[2] - m[2]) * (o[2] - m[2]));
+}
+float farthestOrigin(const rtx_ctx *c, const float *orig, int n) {
+    float far = 0.0f;
+    for (int i = 0; i < n; ++i) far = std::fmax(far, distanceToSpheres(c, orig + 3 * (size_t)i));
+    return far;
+}
+
+// the scene as one launch sees it: the options of the moment, the sphere filters for where its rays start
+DevScene sceneForLaunch(const rtx_ctx *c, float origin_reach) {
+    DevScene s = c->dev;
+    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    sphereGateBounds(c, s, origin_reach);
+    return s;
+}
+
 using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
                               unsigned *, unsigned *, unsigned char *, Counters *);
 const RenderKernel kRenderKernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
@@ -904,8 +961,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
     const long long n_tiles = (long long)tiles_x * tiles_y;
     if (n_tiles > (long long)kTileMask || (size_t)n_tiles > m.cap) return fail(RTX_E_LIMIT, "frame too large for one launch");
-    DevScene s = c->dev;
-    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    const DevScene s = sceneForLaunch(c, distanceToSpheres(c, cam->origin));
     // Longest tiles first.  Every frame records what each of its tiles cost.  A frame of the same frame
     // description whose camera is the previous frame's or close to it gets its list from those costs, and
     // a frame of exactly the view a list was built for reuses the list.  Anything else -- the first
@@ -924,7 +980,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     const unsigned *order = how == kNatural ? nullptr : m.entries;
     const unsigned *list_hdr = how == kNatural ? nullptr : m.list_hdr;
     // the general build of the kernel only where it is needed: a large sphere set, several samples per pixel
-    const bool wide = c->big_spheres || c->spp > 1;
+    const bool wide = c->big_spheres || c->spp > 1 || c->long_lists;
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     const int resident = c->resident_blocks[variant];
     const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
@@ -969,7 +1025,7 @@ using WfShadowKernel = void (*)(DevScene, WfArgs, Counters *);
 using WfShadeKernel = void (*)(DevScene, DevFrame, WfArgs, Counters *);
 const WfTraceKernel kWfTrace[4] = {k_wf_trace<false, false>, k_wf_trace<true, false>, k_wf_trace<false, true>, k_wf_trace<true, true>};
 const WfShadowKernel kWfShadow[4] = {k_wf_shadow<false, false>, k_wf_shadow<true, false>, k_wf_shadow<false, true>, k_wf_shadow<true, true>};
-const WfShadeKernel kWfShade[2] = {k_wf_shade<false>, k_wf_shade<true>};
+const WfShadeKernel kWfShade[4] = {k_wf_shade<false, false>, k_wf_shade<true, false>, k_wf_shade<false, true>, k_wf_shade<true, true>};
 
 int wavefrontBlocks(rtx_ctx *c) {
     hipDeviceProp_t prop;
@@ -985,7 +1041,7 @@ int wavefrontBlocks(rtx_ctx *c) {
         HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWfShadow[v], kBlock, lds));
         c->wf_blocks[1][v] = (per_cu > 0 ? per_cu : 1) * cus;
     }
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 4; ++v) {
         int per_cu = 0;
         HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWfShade[v], kBlock, 0));
         c->wf_blocks[2][v] = (per_cu > 0 ? per_cu : 1) * cus;
@@ -1093,10 +1149,9 @@ int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsig
     const int D = f->depth;
     if (int e = wavefrontBuffers(c, D, (size_t)n_tiles * 64 * c->spp, c->spp)) return e;
     const WfMem &w = c->wf;
-    DevScene s = c->dev;
-    s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
+    const DevScene s = sceneForLaunch(c, distanceToSpheres(c, cam->origin));
     const DevCamera dcam = devCamera(cam);
-    const bool wide = c->big_spheres || c->spp > 1;
+    const bool wide = c->big_spheres || c->spp > 1 || c->long_lists;
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
@@ -1135,7 +1190,7 @@ int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsig
             hipLaunchKernelGGL(kWfShadow[variant], grid(c->wf_blocks[1][variant], (samples << l) * (unsigned)std::max(1, s.n_lights)), dim3(kBlock), lds,
                                stream, s, wfArgs(w, l, 1), c->d_counters);
             mark("shadow");
-            hipLaunchKernelGGL(kWfShade[c->stats ? 1 : 0], grid(c->wf_blocks[2][c->stats ? 1 : 0], samples << l), dim3(kBlock), 0, stream, s, fr,
+            hipLaunchKernelGGL(kWfShade[variant], grid(c->wf_blocks[2][variant], samples << l), dim3(kBlock), 0, stream, s, fr,
                                wfArgs(w, l, 2), c->d_counters);
             mark("shade");
         }
@@ -1367,12 +1422,12 @@ int rtx_commit(rtx_ctx *c) {
     if (c->committed) return fail(RTX_E_STATE, "already committed");
     if (c->sky_w == 0) return fail(RTX_E_STATE, "rtx_commit: no environment map (the reference cannot render without one)");
     if (c->materials.empty()) return fail(RTX_E_STATE, "rtx_commit: no materials");
-    if ((int)c->materials.size() > kMaxMaterials || (int)c->lights.size() > kMaxLights || (int)c->tri_mat.size() > kMaxSmallPrims ||
-        (int)c->box_mat.size() > kMaxSmallPrims || (int)c->islands.size() > kMaxSmallPrims)
-        return fail(RTX_E_LIMIT, "rtx_commit: the analytic lists are staged in LDS: at most 32 materials, 8 lights and 16 loose "
-                                 "triangles / boxes / islands each (larger triangle sets belong in rtx_set_mesh; spheres have no limit)");
+    c->long_lists = (int)c->materials.size() > kMaxMaterials || (int)c->lights.size() > kMaxLights || (int)c->tri_mat.size() > kMaxSmallPrims ||
+                    (int)c->box_mat.size() > kMaxSmallPrims || (int)c->islands.size() > kMaxSmallPrims;
     if (c->spheres.size() > (size_t)kMaxSpheres) return fail(RTX_E_LIMIT, "rtx_commit: more than 16 777 216 spheres");
     if (int e = bind(c)) return e;
+    for (void *p : c->owned) (void)hipFree(p);  // (what a commit that failed half-way left behind)
+    c->owned.clear();
     DevScene &d = c->dev;
     memset(&d, 0, sizeof d);
     Material *dm;
@@ -1434,6 +1489,21 @@ int rtx_commit(rtx_ctx *c) {
     // the slack for the rounding of the sphere test is added per ray by the walk).
     d.sphere_bvh = nullptr;
     c->big_spheres = (int)c->spheres.size() > kMaxSmallPrims;
+    if (!c->spheres.empty() && !c->big_spheres) {  // what the per-ray slack of the sphere gates is worked out from
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, rmax = 0.0f, h2 = 0.0f;
+        for (const float4 &sp : c->spheres) {
+            const float c3[3] = {sp.x, sp.y, sp.z}, r = std::fabs(sp.w);
+            rmax = std::fmax(rmax, r);
+            for (int k = 0; k < 3; ++k) lo[k] = std::fmin(lo[k], c3[k] - r), hi[k] = std::fmax(hi[k], c3[k] + r);
+        }
+        for (int k = 0; k < 3; ++k) {
+            d.sphere_root_c[k] = 0.5f * (lo[k] + hi[k]);
+            const float h = 0.5f * (hi[k] - lo[k]);
+            h2 += h * h;
+        }
+        d.sphere_root_h = std::sqrt(h2) * 1.001f;
+        d.sphere_rmax = rmax * 1.001f;
+    }
     if (c->big_spheres) {
         std::vector<SahBox> boxes(c->spheres.size());
         SahBox all;
@@ -1497,8 +1567,10 @@ int rtx_commit(rtx_ctx *c) {
         hipError_t he = lbvhBuild(dv, di, nt, c->stream, &r);
         if (he != hipSuccess) return failHip(he, "LBVH build");
         c->owned.push_back(r.tris), c->owned.push_back(r.nodes);
-        // Small meshes get the better tree; the triangle array of the GPU build is kept either way.
-        const bool sah = c->bvh_builder == 2 || (c->bvh_builder == 0 && nt <= kSahAutoMaxTris);
+        // Small meshes get the better tree; the triangle array of the GPU build is kept either way.  A Morton
+        // tree deeper than the traversal stack (many triangles in one Morton cell) is replaced as well: the
+        // surface-area builder bounds its depth.
+        const bool sah = c->bvh_builder == 2 || (c->bvh_builder == 0 && nt <= kSahAutoMaxTris) || r.max_depth > kStackDepth;
         if (sah) {
             std::vector<BvhNode> nodes;
             SahBuilder builder(c->mesh_verts, c->mesh_idx, kBvhPad);
@@ -1536,7 +1608,6 @@ int rtx_commit(rtx_ctx *c) {
         auto join = [&](const float *lo, const float *hi) {
             for (int k = 0; k < 3; ++k) u[k] = std::fmin(u[k], lo[k]), u[3 + k] = std::fmax(u[3 + k], hi[k]);
         };
-        if (!c->spheres.empty()) join(d.sphere_bounds, d.sphere_bounds + 3);
         if (!c->tris.empty()) join(d.tri_bounds, d.tri_bounds + 3);
         if (!c->boxes.empty()) join(d.box_bounds, d.box_bounds + 3);
         if (d.n_mesh_tris > 0) {
@@ -1547,6 +1618,8 @@ int rtx_commit(rtx_ctx *c) {
             }
             join(lo, hi);
         }
+        for (int k = 0; k < 6; ++k) c->bounded_objects[k] = u[k];  // (what sphereGateBounds joins the spheres' box with per launch)
+        if (!c->spheres.empty()) join(d.sphere_bounds, d.sphere_bounds + 3);
         float *r = d.island_rect;
         r[0] = r[2] = 3.0e38f, r[1] = r[3] = -3.0e38f;
         for (const float4 &is : c->islands) {  // cx, cz, a, b: the reference's own rectangle is cx -+ a, cz -+ b
@@ -1684,9 +1757,8 @@ int rtx_trace_rays(rtx_ctx *c, const float *orig, const float *dir, int n, int d
         (e = hipMemcpy(d_d, dir, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         rc = failHip(e, "rtx_trace_rays");
     } else {
-        DevScene s = c->dev;
-        s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-        if (c->big_spheres) hipLaunchKernelGGL(k_trace_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
+        const DevScene s = sceneForLaunch(c, farthestOrigin(c, orig, n));
+        if (c->big_spheres || c->long_lists) hipLaunchKernelGGL(k_trace_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
         else hipLaunchKernelGGL(k_trace_rays<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, depth, d_c);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
             (e = hipMemcpy(rgb_out, d_c, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
@@ -1710,9 +1782,8 @@ int rtx_intersect_rays(rtx_ctx *c, const float *orig, const float *dir, int n, f
         (e = hipMemcpy(d_d, dir, bytes, hipMemcpyHostToDevice)) != hipSuccess) {
         rc = failHip(e, "rtx_intersect_rays");
     } else {
-        DevScene s = c->dev;
-        s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-        if (c->big_spheres) hipLaunchKernelGGL(k_intersect_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
+        const DevScene s = sceneForLaunch(c, farthestOrigin(c, orig, n));
+        if (c->big_spheres || c->long_lists) hipLaunchKernelGGL(k_intersect_rays<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
         else hipLaunchKernelGGL(k_intersect_rays<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, s, d_o, d_d, n, d_c);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
             (e = hipMemcpy(out16, d_c, obytes, hipMemcpyDeviceToHost)) != hipSuccess)

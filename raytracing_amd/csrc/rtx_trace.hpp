@@ -325,7 +325,10 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
             walked = true;
         }
     }
-    // one filter for everything that has a bounding box: most rays of an open scene miss it all
+    // One filter for everything that has a bounding box: most rays of an open scene miss it all.  (For every
+    // launch the host sizes object_bounds and sphere_bounds with the slack that the rounding of
+    // Sphere::rayIntersect calls for at the largest distance a ray of that launch can start from -- see
+    // sphereWalk and sphereGateBounds -- so the two filters never reject a ray whose sphere test would pass.)
     if (!walked && !slabMaybe(s.object_bounds, s.object_bounds + 3, orig, inv)) return false;
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
@@ -343,28 +346,38 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     // trianglesIntersect, :304-317
     if (s.n_tris > 0 && !(minDist < t_exit) && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
-        for (int i = 0; i < s.n_tris; ++i) {
-            const float *t = q.tris + 9 * i;
+        auto test = [&](const float *t, int i) {
             const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
             float curDist = 0.0f;
             if (triHit(v0, v1 - v0, v2 - v0, orig, dir, curDist) && curDist < minDist) {
                 minDist = curDist;
                 kind = 2, index = i;
             }
+        };
+        const int n_staged = s.n_tris < kMaxSmallPrims ? s.n_tris : kMaxSmallPrims;
+        for (int i = 0; i < n_staged; ++i) test(q.tris + 9 * i, i);
+        if constexpr (WIDE) {
+#pragma unroll 1
+            for (int i = kMaxSmallPrims; i < s.n_tris; ++i) test(s.tris + 9 * (size_t)i, i);
         }
     }
     // cubesIntersect, :382-397
     if (s.n_boxes > 0 && !(minDist < t_exit) && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
-        for (int i = 0; i < s.n_boxes; ++i) {
-            const float *b = q.boxes + 6 * i;
+        auto test = [&](const float *b, int i) {
             const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
-            if (!slabMaybe(lo, hi, orig, inv)) continue;
+            if (!slabMaybe(lo, hi, orig, inv)) return;
             RTX_COUNT(CNT_BOX_TESTS);
             float curDist = 0.0f;
             if (boxSlab(lo, hi, orig, dir, curDist) && curDist < minDist) {
                 minDist = curDist;
                 kind = 3, index = i;
             }
+        };
+        const int n_staged = s.n_boxes < kMaxSmallPrims ? s.n_boxes : kMaxSmallPrims;
+        for (int i = 0; i < n_staged; ++i) test(q.boxes + 6 * i, i);
+        if constexpr (WIDE) {
+#pragma unroll 1
+            for (int i = kMaxSmallPrims; i < s.n_boxes; ++i) test(s.boxes + 6 * (size_t)i, i);
         }
     }
     cs.minDist = minDist, cs.kind = kind, cs.index = index;
@@ -408,7 +421,7 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
             // the rectangle around all islands first (padded; the exact conditions follow per island)
             const bool near_islands = pt.x > s.island_rect[0] && pt.x < s.island_rect[1] && pt.z > s.island_rect[2] && pt.z < s.island_rect[3];
             for (int i = 0; near_islands && i < s.n_islands; ++i) {
-                const float4 is = q.islands[i];  // cx, cz, a, b
+                const float4 is = islandAt<WIDE>(s, q, i);  // cx, cz, a, b
                 // the bounding-rectangle conditions come first in the reference's && chain as well; the
                 // two divisions of the ellipse test are only paid inside the rectangle
                 if (pt.x > is.x - is.z && pt.x < is.x + is.z && pt.z > is.y - is.w && pt.z < is.y + is.w && dist < minDist) {
@@ -435,15 +448,15 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
         else sp = q.spheres[index], mat = q.sphere_mat[index];
         h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
     } else if (kind == 2) {
-        const float *t = q.tris + 9 * index;
+        const float *t = triAt<WIDE>(s, q, index);
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
         h.N = triNormal(v1 - v0, v2 - v0);
-        mat = q.tri_mat[index];
+        mat = triMatAt<WIDE>(s, q, index);
     } else if (kind == 3) {
-        const float *b = q.boxes + 6 * index;
+        const float *b = boxAt<WIDE>(s, q, index);
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
         h.N = boxNormal(lo, hi, h.point);
-        mat = q.box_mat[index];
+        mat = boxMatAt<WIDE>(s, q, index);
     } else if (kind == 4) {
         const float4 *tp = s.mesh_tris + 3 * (size_t)index;
         const float4 p1 = tp[1], p2 = tp[2];
@@ -456,7 +469,7 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
         h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.island_mat;
     }
-    h.m = q.materials[mat];
+    h.m = materialAt<WIDE>(s, q, mat);
     h.mat_index = mat;
     if (kind == 5) {
         // texture tiles every `scale` units, nearest texel, blend (tex*0.3 + diffuse)/2: src/Scene.cpp:46-51
@@ -586,9 +599,10 @@ struct LightAim {
     bool counts;  // false: the light can add to neither sum, its shadow ray decides nothing
 };
 
+template <bool WIDE = false>
 RTX_DEV LightAim aimLight(const DevScene &s, const SmallScene &q, const PathState &st, int li) {
     LightAim a;
-    const float4 L = q.lights[li];
+    const float4 L = lightAt<WIDE>(s, q, li);
     a.pos = v3(L.x, L.y, L.z);
     a.intensity = L.w;
     a.dir = normalize(a.pos - st.point);
@@ -649,7 +663,7 @@ RTX_DEV int quadBroadcast(int v) {
 // Consumes the result of the pending ray (hit, h, md: what castEnd returned; hit = false when the ray
 // was not cast) and sets up the next one.  Returns true when the whole tree is done; `color` is
 // then the value traceRay would have returned.
-template <bool STATS>
+template <bool STATS, bool WIDE = false>
 RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool hit, const Hit &h, float md,
                          int quad_j, V3 &color, LaneCounters<STATS> &lc) {
     const bool shadow = st.light >= 0;
@@ -659,7 +673,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         // ---- after the shadow ray of light st.light ----
         if (!pathShadowed(st, hit, md)) {
             RTX_COUNT(CNT_LIT);
-            pathAddLight(q, st, st.dir, st.ndl, q.lights[st.light].w);
+            pathAddLight(q, st, st.dir, st.ndl, lightAt<WIDE>(s, q, st.light).w);
         }
         ++st.light;
     } else if (shadow) {
@@ -672,7 +686,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
             const int li = st.light + k;
             if (li < s.n_lights && ((st.cast_mask >> k) & 1) && !hidden[k]) {
                 if constexpr (STATS) lc.v[CNT_LIT] += count ? 1u : 0u;
-                const float4 L = q.lights[li];
+                const float4 L = lightAt<WIDE>(s, q, li);
                 const V3 lightDir = normalize(v3(L.x, L.y, L.z) - st.point);
                 pathAddLight(q, st, lightDir, dot(lightDir, st.N), L.w);
             }
@@ -691,7 +705,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         // ---- the next shadow ray(s) ----
         while (st.light < s.n_lights) {
             if (quad_j < 0) {
-                const LightAim a = aimLight(s, q, st, st.light);
+                const LightAim a = aimLight<WIDE>(s, q, st, st.light);
                 if (!a.counts) {
                     ++st.light;
                     continue;
@@ -703,7 +717,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (st.light + k < s.n_lights) {
-                    const LightAim a = aimLight(s, q, st, st.light + k);
+                    const LightAim a = aimLight<WIDE>(s, q, st, st.light + k);
                     if (a.counts) {
                         mask |= 1 << k;
                         if (k == quad_j) pathAimShadowRay(s, st, a);
@@ -800,7 +814,7 @@ RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int
             pathCountRay<STATS>(st, -1, lc);
             hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
         }
-        if (pathConsume<STATS>(s, q, st, frames, hit, h, md, -1, color, lc)) return color;
+        if (pathConsume<STATS, WIDE>(s, q, st, frames, hit, h, md, -1, color, lc)) return color;
     }
 }
 

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_trace(DevScene s, 
             PathState st;
             st.point = h.point, st.N = h.N, st.m = h.m, st.view = dir;
             for (int li = 0; li < s.n_lights; ++li) {
-                const LightAim aim = aimLight(s, q, st, li);
+                const LightAim aim = aimLight<WIDE>(s, q, st, li);
                 if (!aim.counts) continue;
                 cast_mask |= 1u << li;
                 const V3 off = st.N * s.fprec;  // the shadow ray's origin, as pathAimShadowRay forms it
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_shadow(DevScene s,
         PathState st;
         st.point = v3(f0.x, f0.y, f0.z), st.N = v3(f1.x, f1.y, f1.z);
         // the same three values aimLight produced when the request was made (src/Scene.cpp:65)
-        const float4 L = q.lights[li];
+        const float4 L = lightAt<WIDE>(s, q, (int)li);
         LightAim aim;
         aim.pos = v3(L.x, L.y, L.z), aim.intensity = L.w;
         aim.dir = normalize(aim.pos - st.point);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_shadow(DevScene s,
     flushCounters<STATS>(lc, counters);
 }
 
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, WfArgs a, Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
             const float4 f0 = a.fat[4 * (size_t)i], f1 = a.fat[4 * (size_t)i + 1], f2 = a.fat[4 * (size_t)i + 2], f3 = a.fat[4 * (size_t)i + 3];
             PathState st;
             st.point = v3(f0.x, f0.y, f0.z), st.N = v3(f1.x, f1.y, f1.z), st.view = v3(f2.x, f2.y, f2.z);
-            st.m = q.materials[__float_as_int(f0.w)];
+            st.m = materialAt<WIDE>(s, q, __float_as_int(f0.w));
             st.m.dr = f3.x, st.m.dg = f3.y, st.m.db = f3.z;
             st.Ld = 0.0f, st.Ls = 0.0f;
             const unsigned lit = __float_as_uint(f2.w) & ~__float_as_uint(f1.w);  // cast and not hidden
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
             for (int li = 0; li < s.n_lights; ++li) {
                 if (!((lit >> li) & 1u)) continue;
                 RTX_COUNT(CNT_LIT);
-                const float4 L = q.lights[li];
+                const float4 L = lightAt<WIDE>(s, q, li);
                 const V3 lightDir = normalize(v3(L.x, L.y, L.z) - st.point);
                 pathAddLight(q, st, lightDir, dot(lightDir, st.N), L.w);
             }

@@ -61,6 +61,9 @@ class ShardedRenderer:
         # frame k runs while frame k+1 is being rendered (buffers are double).
         self.stream = torch.cuda.Stream(self.device)
         self.comm = torch.cuda.Stream(self.device)
+        # the zero-fills above were enqueued on the caller's current stream: nothing of ours may overtake them
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self.comm.wait_stream(torch.cuda.current_stream(self.device))
 
     def render(self, cam):
         """One frame.  Enqueues the render of this rank's rows, the gather and (rank 0) the

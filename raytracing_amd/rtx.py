@@ -12,6 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_PKG, "librtx_hip.so")
+HIP_FAST_LIB_PATH = os.path.join(_PKG, "librtx_hip_fast.so")  # the tolerance build of the same sources (see build.py)
 ASSETS_DIR = os.path.join(os.path.dirname(_PKG), "assets")
 
 MASK_SPHERES, MASK_CUBES, MASK_TRIANGLES, MASK_MODEL, MASK_ISLANDS, MASK_ALL = 1, 2, 4, 8, 16, 31
@@ -53,7 +54,8 @@ class Stats(C.Structure):
 RTX_SYMBOLS = ["rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_option", "rtx_set_materials", "rtx_set_lights",
                "rtx_set_spheres", "rtx_set_boxes", "rtx_set_triangles", "rtx_set_mesh", "rtx_set_islands", "rtx_set_water",
                "rtx_set_envmap", "rtx_commit", "rtx_render", "rtx_render_device", "rtx_render_device_noalloc", "rtx_get_stats", "rtx_frame_rows",
-               "rtx_deinterleave_rows_device", "rtx_trace_rays", "rtx_intersect_rays"]
+               "rtx_deinterleave_rows_device", "rtx_trace_rays", "rtx_intersect_rays", "rtx_group_create", "rtx_group_destroy",
+               "rtx_group_size", "rtx_group_ctx", "rtx_group_commit", "rtx_group_render", "rtx_group_last_error"]
 HOST_SYMBOLS = ["rt_default_materials", "rt_material_index", "rt_default_camera", "rt_load_model", "rt_free",
                 "rt_decode_jpeg", "rt_scene_load_default", "rt_scene_load_default_tex", "rt_save_bmp", "rt_main",
                 "rt_host_last_error"]
@@ -82,6 +84,13 @@ _SIGNATURES = {
     "rtx_deinterleave_rows_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rtx_trace_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "rtx_intersect_rays": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "rtx_group_create": (_i, [C.POINTER(_vp), _vp, _i]),
+    "rtx_group_destroy": (None, [_vp]),
+    "rtx_group_size": (_i, [_vp]),
+    "rtx_group_ctx": (_vp, [_vp, _i]),
+    "rtx_group_commit": (_i, [_vp]),
+    "rtx_group_render": (_i, [_vp, C.POINTER(Camera), _i, _i, _i, _vp, C.POINTER(Stats)]),
+    "rtx_group_last_error": (C.c_char_p, []),
     "rt_default_materials": (_i, [_vp]),
     "rt_material_index": (_i, [C.c_char_p]),
     "rt_default_camera": (_i, [C.POINTER(Camera)]),
@@ -170,16 +179,18 @@ class Backend:
 class Context:
     """One rtx_ctx.  Scene setters take numpy arrays; render returns a (rows, W, 3) uint8 BGR array."""
 
-    def __init__(self, backend, device=0):
+    def __init__(self, backend, device=0, handle=None):
         self.backend = backend
         self.lib = backend.lib
-        self.handle = _vp()
-        backend.check(self.lib.rtx_create(C.byref(self.handle), device))
+        self.owned = handle is None  # contexts of a Group belong to the group
+        self.handle = _vp() if handle is None else _vp(handle)
+        if handle is None:
+            backend.check(self.lib.rtx_create(C.byref(self.handle), device))
 
     def close(self):
-        if self.handle:
+        if self.handle and self.owned:
             self.lib.rtx_destroy(self.handle)
-            self.handle = _vp()
+        self.handle = _vp()
 
     def __del__(self):
         try:
@@ -301,7 +312,46 @@ class Context:
         return out
 
 
+class Group:
+    """One rtx_group: several ranks (one GPU each; ids may repeat) rendering row-interleaved shares of a frame,
+    gathered on the first one.  `contexts` are the ranks' Context objects: set the same scene on each."""
+
+    def __init__(self, backend, device_ids):
+        self.backend, self.lib = backend, backend.lib
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self.handle = _vp()
+        self._ck(self.lib.rtx_group_create(C.byref(self.handle), ids, len(device_ids)))
+        self.contexts = [Context(backend, handle=self.lib.rtx_group_ctx(self.handle, r)) for r in range(len(device_ids))]
+
+    def _ck(self, code):
+        if code != 0:
+            raise RtxError(code, (self.lib.rtx_group_last_error() or b"").decode("utf-8", "replace"))
+
+    def commit(self):
+        self._ck(self.lib.rtx_group_commit(self.handle))
+
+    def render(self, cam, width, height, depth=4, want_stats=False):
+        out = np.zeros((height, width, 3), np.uint8)
+        st = Stats()
+        self._ck(self.lib.rtx_group_render(self.handle, C.byref(cam), width, height, depth, out.ctypes.data, C.byref(st)))
+        return (out, st) if want_stats else out
+
+    def close(self):
+        if self.handle:
+            for c in self.contexts:
+                c.handle = _vp()
+            self.lib.rtx_group_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _hip = None
+_hip_fast = None
 
 
 def hip_backend():
@@ -311,6 +361,16 @@ def hip_backend():
         _load_torch_first()
         _hip = Backend(HIP_LIB_PATH)
     return _hip
+
+
+def hip_fast_backend():
+    """The tolerance build (fused multiply-add, fast division / square root / powf): same sources, same C ABI,
+    frames within PSNR >= 50 dB / 99.9 % of pixels within 1/255 of the bit-faithful build's instead of equal."""
+    global _hip_fast
+    if _hip_fast is None:
+        _load_torch_first()
+        _hip_fast = Backend(HIP_FAST_LIB_PATH)
+    return _hip_fast
 
 
 def _load_torch_first():

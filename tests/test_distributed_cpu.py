@@ -70,3 +70,24 @@ def test_row_interleaved_gather_reassembles_the_frame(tmp_path, world):
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     frame, whole = np.load(out)
     assert np.array_equal(frame, whole)
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+def test_group_api_reassembles_the_frame_on_the_oracle(oracle_backend, textures, n_ranks):
+    """rtx_group_* on the oracle build (a "device" is just another context): rank r renders rows r, r + n, ...;
+    the group's frame equals the frame of a single context, and the ray counts add up."""
+    from conftest import make_default_context
+    from raytracing_amd.rtx import OPT_STATS, Group
+    W, H, D = 80, 53, 3
+    cam = oracle_backend.default_camera()
+    single = make_default_context(oracle_backend, textures, mask=17, sky="map.jpg", options=[(OPT_STATS, 1)])
+    want, want_st = single.render(cam, W, H, D, want_stats=True)
+    g = Group(oracle_backend, [0] * n_ranks)
+    for ctx in g.contexts:
+        ctx.load_default_scene(textures["water"], textures["map.jpg"], mask=17)
+        ctx.set_option(OPT_STATS, 1)
+    g.commit()
+    got, st = g.render(cam, W, H, D, want_stats=True)
+    assert np.array_equal(got, want)
+    assert (st.primary_rays, st.secondary_rays, st.shadow_rays) == (want_st.primary_rays, want_st.secondary_rays, want_st.shadow_rays)
+    g.close()

@@ -157,6 +157,61 @@ def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures, 
     assert abs(out[0, 3] + 20.0) < 1e-5  # the nearest layer
 
 
+def test_clustered_large_mesh_with_an_outlier_builds(hip, oracle_backend, textures):
+    """300 000 small triangles inside one Morton cell plus one triangle far away: the Morton-order tree gets
+    deeper than the traversal stack; the commit must then fall back to the depth-bounded surface-area builder
+    instead of failing, and the hits must equal the oracle's."""
+    rng = np.random.default_rng(9)
+    n = 300_000
+    c = np.float32([0, 0, -30]) + rng.uniform(-0.5, 0.5, (n, 1, 3)).astype(np.float32)
+    tri = c + rng.normal(scale=0.02, size=(n, 3, 3)).astype(np.float32)
+    far = np.float32([[[4000, 4000, -9000], [4001, 4000, -9000], [4000, 4001, -9000]]])
+    verts = np.ascontiguousarray(np.concatenate([tri, far]).reshape(-1, 3))
+    idx = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    m = 96
+    target = np.float32([0, 0, -30]) + rng.uniform(-0.45, 0.45, (m, 3)).astype(np.float32)
+    o = np.zeros((m, 3), np.float32)
+    d = target / np.linalg.norm(target, axis=1, keepdims=True)
+    out = []
+    for b in (hip, oracle_backend):
+        ctx = b.create()
+        ctx.set_materials(b.default_materials())
+        ctx.set_mesh(verts, idx, 3)
+        ctx.set_envmap(textures["map.jpg"])
+        ctx.set_option(OPT_MESH_GRID, 0)  # (the grid would put every triangle into a handful of cells; not the point here)
+        ctx.commit()
+        out.append(ctx.intersect_rays(o, np.ascontiguousarray(d, np.float32)))
+    assert (out[1][:, 0] > 0).sum() > 20
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+def test_tiny_distant_sphere_in_a_small_set(hip, oracle_backend, textures):
+    """Sphere::rayIntersect's rounding grows with the square of the distance to the centre: a sphere of radius
+    0.05 some 200 units away is "hit" by rays that pass well outside its box.  The box filters in front of the
+    sphere loop must not reject what the reference's test accepts (sets of up to 16 spheres take this path)."""
+    rng = np.random.default_rng(21)
+    centres = np.float32([[150, 40, -120], [-90, 10, -170], [0.5, 0.2, -3.0]])
+    radii = np.float32([0.05, 0.02, 0.4])
+    n = 60_000
+    which = rng.integers(0, 2, n)
+    o = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    aim = centres[which] + rng.normal(scale=1.0, size=(n, 3)).astype(np.float32) * (radii[which][:, None] * 3)
+    d = aim - o
+    d = np.ascontiguousarray(d / np.linalg.norm(d, axis=1, keepdims=True), np.float32)
+    out = []
+    for b in (hip, oracle_backend):
+        ctx = b.create()
+        ctx.set_materials(b.default_materials())
+        ctx.set_spheres(centres, radii, [2, 3, 4])
+        ctx.set_envmap(textures["map.jpg"])
+        ctx.commit()
+        out.append(ctx.intersect_rays(o, d))
+    hits = out[1][:, 0] > 0
+    assert hits.sum() > 500
+    assert np.array_equal(out[0][:, 0], out[1][:, 0])
+    assert np.array_equal(out[0][hits].view(np.uint32), out[1][hits].view(np.uint32))
+
+
 def test_axis_parallel_rays_through_the_bvh(hip, oracle_backend, textures):
     """Direction components that are exactly 0 (1/0 in the box tests) must not lose hits."""
     verts, idx = _soup(3000, 77)
@@ -295,19 +350,44 @@ def test_random_scenes_equal_the_oracle(hip, oracle_backend, textures, seed):
         assert np.array_equal(f, frames[0])
 
 
-def test_commit_rejects_lists_beyond_the_lds_staging(hip, textures):
-    for what in ("boxes", "lights", "materials"):
-        ctx = hip.create()
-        mats = np.tile(hip.default_materials()[:1], (33 if what == "materials" else 4, 1))
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_lists_longer_than_the_lds_staging_equal_the_oracle(hip, oracle_backend, textures, pipeline):
+    """The reference's lists have no length limit.  100 boxes, 40 loose triangles, 20 islands, 20 lights and
+    40 materials: beyond what the kernels stage in LDS (16 / 16 / 16 / 8 / 32), so the tails come from
+    global memory -- same frame as the oracle's, in both pipelines, all scheduling regimes."""
+    from raytracing_amd.rtx import OPT_PIPELINE
+    rng = np.random.default_rng(77)
+    n_mat = 40
+    mats = np.zeros((n_mat, 9), np.float32)
+    mats[:, 0] = rng.uniform(1.0, 1.6, n_mat)
+    mats[:, 1:5] = rng.uniform(0, 1, (n_mat, 4)) * (rng.uniform(size=(n_mat, 4)) > 0.4)
+    mats[:, 5:8] = rng.uniform(0, 1, (n_mat, 3))
+    mats[:, 8] = rng.choice([10.0, 50.0, 125.0], n_mat)
+    centre = np.array([0.0, -1.0, -24.0])
+    lights = np.concatenate([rng.uniform(-30, 30, (20, 3)) + [0, 40, 0], rng.uniform(0.05, 0.3, (20, 1))], 1)
+    a = centre + rng.uniform(-14, 14, (100, 3)) * [1, 0.4, 1]
+    boxes = (a, a + rng.uniform(0.3, 1.5, (100, 3)), rng.integers(0, n_mat, 100))
+    c = centre + rng.uniform(-12, 12, (40, 1, 3)) * [1, 0.4, 1]
+    tris = ((c + rng.normal(scale=1.5, size=(40, 3, 3))).reshape(40, 9), rng.integers(0, n_mat, 40))
+    isl = np.concatenate([rng.uniform(-30, 30, (20, 1)), rng.uniform(-50, -8, (20, 1)), rng.uniform(1, 4, (20, 2))], 1)
+    frames = []
+    for b in (oracle_backend, hip):
+        ctx = b.create()
         ctx.set_materials(mats)
-        if what == "boxes":
-            ctx.set_boxes(np.zeros((17, 3)), np.ones((17, 3)), np.zeros(17, np.int32))
-        if what == "lights":
-            ctx.set_lights(np.ones((9, 4)))
-        ctx.set_envmap(textures["map.jpg"])
-        with pytest.raises(RtxError) as e:
-            ctx.commit()
-        assert e.value.code == -5
+        ctx.set_lights(lights)
+        ctx.set_boxes(*boxes)
+        ctx.set_triangles(*tris)
+        ctx.set_islands(isl, -4.0, 39, [0.2, 0.5, 0.1], [0.1, 0.3, 0.05])
+        ctx.set_water(textures["water"], -4.5, 10.0, 35)
+        ctx.set_envmap(textures["map.jpg"], 100)
+        if b is hip:
+            ctx.set_option(OPT_PIPELINE, pipeline)
+        ctx.commit()
+        for _ in range(1 if b is oracle_backend else 3):
+            frames.append(ctx.render(b.default_camera(), 256, 192, 3))
+    assert len(np.unique(frames[0].reshape(-1, 3), axis=0)) > 500  # the scene is really in view
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
 
 
 def test_api_errors(hip, textures):
