@@ -105,10 +105,11 @@ enum rtx_option {
                                  colours stay finite (x + 0*c == x needs a finite c)                */
     RTX_OPT_FAR_CLIP = 3,     /* float bits: sceneIntersect's `minDist < 700` (src/Scene.cpp:57)   */
     RTX_OPT_SURFACE_BIAS = 4, /* float bits: fprec = 1e-3 (include/Scene.h:23)                     */
-    RTX_OPT_BVH_BUILDER = 6,  /* before rtx_commit: 0 (default) = surface-area heuristic on the host
-                                 for meshes up to 262 144 triangles, Morton order on the GPU above;
-                                 1 = always Morton order on the GPU; 2 = always surface-area
-                                 heuristic.  The tree only steers the walk: results do not change */
+    RTX_OPT_BVH_BUILDER = 6,  /* before rtx_commit, who builds the mesh's bounding volume hierarchy: 0 (default) =
+                                 the GPU, top-down by the binned surface-area heuristic; 1 = the GPU, the plain
+                                 Morton-order hierarchy; 3 = the GPU, agglomerative clustering along the Morton
+                                 order; 2 = the host, surface-area heuristic.  The tree only steers the walk:
+                                 results do not change                                                 */
     RTX_OPT_SCHEDULE_FEEDBACK = 7, /* 0/1 (default 1): a frame whose camera is the previous frame's or
                                  close to it (and whose frame description is the same) starts its
                                  tiles in the order of what they cost in that frame; 0 = always the

@@ -16,9 +16,6 @@ namespace rtx {
 // triangle the exact float test accepts: the rounding of (b - o) * (1/d) is a few ulp of the
 // coordinates involved, far below this.
 constexpr float kBvhPad = 2e-5f;
-// rtx_commit builds meshes up to this many triangles with the surface-area heuristic on the host
-// (sah_build.hpp) unless told otherwise; larger ones keep the tree built here.
-constexpr int kSahAutoMaxTris = 1 << 18;
 
 struct Aabb {
     float lo[3], hi[3];
@@ -241,6 +238,11 @@ __global__ void k_lbvh_single(const Aabb *__restrict__ tri_box, BvhNode *__restr
     out[0] = nd;
 }
 
+}  // namespace rtx
+#include "ploc_build.hpp"
+#include "sah_gpu_build.hpp"
+namespace rtx {
+
 struct LbvhResult {
     float4 *tris = nullptr;   // 3 x float4 per triangle
     BvhNode *nodes = nullptr; // max(n - 1, 1) nodes
@@ -259,7 +261,12 @@ struct LbvhResult {
 
 // Builds the tree on `stream`.  verts/idx are device pointers.  On success the caller owns
 // out->tris and out->nodes (hipFree).  Returns hipSuccess or the first failing HIP call's code.
-inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, hipStream_t stream, LbvhResult *out) {
+// What to build besides the triangle array: nothing (the caller brings a tree of its own), the hierarchy of the
+// Morton codes' common prefixes (Karras), agglomerative clustering along the Morton order (ploc_build.hpp), or
+// the top-down binned surface-area heuristic (sah_gpu_build.hpp; bounded to `depth_limit` levels).
+enum class GpuTree { kNone, kMorton, kCluster, kSah };
+inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, GpuTree tree, int depth_limit, hipStream_t stream, LbvhResult *out) {
+    const bool cluster = tree == GpuTree::kCluster;
     hipError_t err = hipSuccess;
     const int B = 256;
     const int gridT = (nt + B - 1) / B;
@@ -306,16 +313,24 @@ inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, hipS
     RTX_HIP_TRY(hipMemsetAsync(d_depth, 0, sizeof(int), stream));
     hipLaunchKernelGGL(k_lbvh_prepare, dim3(gridT), dim3(B), 0, stream, d_verts, d_idx, nt, tris, tri_box, centroid, cbounds);
     RTX_HIP_TRY(hipGetLastError());
-    if (nt == 1) {
+    if (tree == GpuTree::kNone) {
+        out->max_depth = 0;
+    } else if (nt == 1) {
         hipLaunchKernelGGL(k_lbvh_single, dim3(1), dim3(64), 0, stream, tri_box, nodes, pad);
         RTX_HIP_TRY(hipGetLastError());
         out->max_depth = 1;
+    } else if (tree == GpuTree::kSah) {
+        RTX_HIP_TRY(sahGpuBuild(d_verts, d_idx, nt, pad, depth_limit, stream, nodes, &out->max_depth));
     } else {
         hipLaunchKernelGGL(k_lbvh_morton, dim3(gridT), dim3(B), 0, stream, centroid, cbounds, nt, keys);
         RTX_HIP_TRY(hipGetLastError());
         RTX_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys, keys_sorted, nt, 0, 62, stream));
         RTX_HIP_TRY(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
         RTX_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys, keys_sorted, nt, 0, 62, stream));
+        if (cluster) {
+            RTX_HIP_TRY(plocBuild<Aabb>(keys_sorted, tri_box, nt, pad, stream, nodes, &out->max_depth));
+            goto built;
+        }
         hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gridT), dim3(B), 0, stream, keys_sorted, nt, left, right, parent_inner, parent_leaf);
         RTX_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_lbvh_refit, dim3(gridT), dim3(B), 0, stream, keys_sorted, nt, tri_box, left, right, parent_inner, parent_leaf, node_box, visits, pad);
@@ -326,6 +341,7 @@ inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, hipS
         RTX_HIP_TRY(hipGetLastError());
         RTX_HIP_TRY(hipMemcpyAsync(&out->max_depth, d_depth, sizeof(int), hipMemcpyDeviceToHost, stream));
     }
+built:
     RTX_HIP_TRY(hipStreamSynchronize(stream));
     out->tris = tris, out->nodes = nodes, out->n_nodes = n_inner;
     tris = nullptr, nodes = nullptr;

@@ -1306,7 +1306,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             break;
         case RTX_OPT_BVH_BUILDER:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
-            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 auto, 1 Morton order on the GPU, 2 surface-area heuristic on the host");
+            if (value > 3) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 surface-area heuristic on the GPU, 1 Morton order on the GPU, 2 surface-area heuristic on the host, 3 clustering on the GPU");
             c->bvh_builder = (int)value;
             break;
         case RTX_OPT_MESH_GRID:
@@ -1563,15 +1563,16 @@ int rtx_commit(rtx_ctx *c) {
         int *di;
         if (int e = upload(c->mesh_verts, &dv, c->owned)) return e;
         if (int e = upload(c->mesh_idx, &di, c->owned)) return e;
+        // RTX_OPT_BVH_BUILDER: the tree is built on the GPU -- top-down by the surface-area heuristic unless one of the
+        // Morton-order builders is asked for -- or, on request, by the host's surface-area builder, which also
+        // steps in when a Morton-order tree comes out deeper than the traversal stack (it bounds its depth).
         LbvhResult r;
-        hipError_t he = lbvhBuild(dv, di, nt, c->stream, &r);
-        if (he != hipSuccess) return failHip(he, "LBVH build");
+        const GpuTree gpu_tree = c->bvh_builder == 2 ? GpuTree::kNone
+                                                      : (c->bvh_builder == 1 ? GpuTree::kMorton : (c->bvh_builder == 3 ? GpuTree::kCluster : GpuTree::kSah));
+        hipError_t he = lbvhBuild(dv, di, nt, gpu_tree, kStackDepth, c->stream, &r);
+        if (he != hipSuccess) return failHip(he, "mesh tree build");
         c->owned.push_back(r.tris), c->owned.push_back(r.nodes);
-        // Small meshes get the better tree; the triangle array of the GPU build is kept either way.  A Morton
-        // tree deeper than the traversal stack (many triangles in one Morton cell) is replaced as well: the
-        // surface-area builder bounds its depth.
-        const bool sah = c->bvh_builder == 2 || (c->bvh_builder == 0 && nt <= kSahAutoMaxTris) || r.max_depth > kStackDepth;
-        if (sah) {
+        if (gpu_tree == GpuTree::kNone || r.max_depth > kStackDepth) {
             std::vector<BvhNode> nodes;
             SahBuilder builder(c->mesh_verts, c->mesh_idx, kBvhPad);
             r.max_depth = builder.build(nodes, kStackDepth);

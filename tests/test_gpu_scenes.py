@@ -78,13 +78,14 @@ def test_mesh_with_grid_cells_equals_oracle_mesh(hip, oracle_backend, textures, 
 
 
 @pytest.mark.parametrize("n_tris", [1, 2, 5, 300, 20000])
-def test_both_tree_builders_give_the_same_hits(hip, textures, n_tris):
-    """Morton-order build on the GPU vs surface-area-heuristic build on the host: the tree only steers
+def test_all_tree_builders_give_the_same_hits(hip, textures, n_tris):
+    """The four builders -- surface-area heuristic on the GPU (the default), Morton-order hierarchy on the GPU,
+    surface-area heuristic on the host, clustering along the Morton order on the GPU: the tree only steers
     the walk, so every hit record must be identical (ties between equal distances included)."""
     verts, idx = _soup(n_tris, 900 + n_tris)
     o, d = _rays(20000, 11 + n_tris)
     out = []
-    for builder in (1, 2):
+    for builder in (0, 1, 2, 3):
         c = hip.create()
         c.set_materials(hip.default_materials())
         c.set_mesh(verts, idx, 3)
@@ -94,7 +95,8 @@ def test_both_tree_builders_give_the_same_hits(hip, textures, n_tris):
         c.commit()
         out.append(c.intersect_rays(o, d))
     assert (out[0][:, 0] > 0).sum() > (0 if n_tris < 300 else 100)
-    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+    for other in out[1:]:
+        assert np.array_equal(out[0].view(np.uint32), other.view(np.uint32))
 
 
 def _subdivide(verts, idx, levels):
@@ -136,7 +138,7 @@ def test_million_triangle_mesh_equals_oracle(hip, oracle_backend, textures):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("builder", [1, 2])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
 def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures, builder):
     """All triangles share one centroid (identical Morton codes, no usable split plane): the tree
     must still be valid."""
