@@ -772,7 +772,10 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                     st.orig = f.rorig, st.dir = f.rdir;
                     f.state = (f.state & ~2) | 4;
                 }
-                frames[st.sp++] = f;
+                // the pending refract ray is only stored when there is one (most nodes have the reflect child alone)
+                Frame &slot = frames[st.sp++];
+                slot.acc = f.acc, slot.a2 = f.a2, slot.a3 = f.a3, slot.state = f.state;
+                if (f.state & 2) slot.rorig = f.rorig, slot.rdir = f.rdir;
                 st.depth = depth - 1;
                 return false;
             }

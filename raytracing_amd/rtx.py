@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG, "librtx_hip.so")
+# (RTX_HIP_LIB: another build of the same library, for A/B measurements)
+HIP_LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_PKG, "librtx_hip.so")
 HIP_FAST_LIB_PATH = os.path.join(_PKG, "librtx_hip_fast.so")  # the tolerance build of the same sources (see build.py)
 ASSETS_DIR = os.path.join(os.path.dirname(_PKG), "assets")
 
