@@ -184,6 +184,53 @@ def cpu_baseline(textures, cam_of, gpu_frame=None):
     }
 
 
+# one rocprofv3 run per group: the SQ block holds 8 counters, FETCH_SIZE and WRITE_SIZE are derived from 3 and 2 TCC counters
+COUNTER_PASSES = ("SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE")
+
+
+def live_counters(workload, frames):
+    """Hardware counters of this build's render kernels on this workload, collected now: scripts/counter_frames.py
+    (the same frames through the C ABI, in a child process) under `rocprofv3 --pmc`, one counter group per run.
+    Called before this process touches a GPU.  Returns {counter: sum over the render kernels per frame}, or None
+    when the profiler is not there, is already wrapped around this process, or a pass fails."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    nested = any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if prof is None or nested:
+        return None
+    out = {}
+    base = tempfile.mkdtemp(prefix="rtx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for i, group in enumerate(COUNTER_PASSES):
+        d = os.path.join(base, "p%d" % i)
+        cmd = ["timeout", "-s", "KILL", "180", prof, "--pmc"] + group.split() + ["-d", d, "-o", "c", "--output-format", "csv", "--",
+               sys.executable, os.path.join(ROOT, "scripts", "counter_frames.py"), workload, str(frames)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=200)
+        except Exception as e:
+            print("counter pass %r failed: %r" % (group, e), file=sys.stderr)
+            return None
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            print("counter pass %r failed (exit %d): %s" % (group, r.returncode, r.stdout.decode(errors="replace")[-300:]), file=sys.stderr)
+            return None
+        kernels = set()
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                m = re.search(r"k_render|k_wf_\w+", row["Kernel_Name"])
+                if m:
+                    kernels.add(m.group(0))
+                    out[row["Counter_Name"]] = out.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"]) / frames
+        out["kernels"] = sorted(kernels)
+    shutil.rmtree(base, ignore_errors=True)
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as sock:
@@ -214,17 +261,23 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic stays null)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region, the ray counts and the roofline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
     args = ap.parse_args()
     global WIDTH, HEIGHT, DEPTH, MASK
     WIDTH, HEIGHT, DEPTH, MASK, workload_text, metric_text = WORKLOADS[args.workload]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)
+    counter_frames = 2 if args.workload == "stress" else 6
+    counters = None
+    if args.gpus == 1 and not args.no_counters:
+        counters = live_counters(args.workload, counter_frames)  # child processes; nothing here has touched a GPU yet
 
     import numpy as np
     import torch
     from raytracing_amd.distributed import ShardedRenderer
-    from raytracing_amd.rtx import ASSETS_DIR, OPT_SCHEDULE_FEEDBACK, OPT_STATS, Frame, hip_backend
+    from raytracing_amd.rtx import ASSETS_DIR, HIP_FAST_LIB_PATH, OPT_SCHEDULE_FEEDBACK, OPT_STATS, Frame, hip_backend, hip_fast_backend
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,11 +297,12 @@ def main():
     cam = hip.default_camera()
     stress = args.workload.startswith("stress")
 
-    def make_ctx(stats=False, options=()):
-        ctx = hip.create(local_rank)
+    def make_ctx(stats=False, options=(), backend=None):
+        backend = backend or hip
+        ctx = backend.create(local_rank)
         if stress:
             from raytracing_amd import scenes
-            scenes.load_stress_scene(ctx, hip, textures["water"], textures["sky"])
+            scenes.load_stress_scene(ctx, backend, textures["water"], textures["sky"])
         else:
             ctx.load_default_scene(textures["water"], textures["sky"], mask=MASK)
         if stats:
@@ -297,6 +351,45 @@ def main():
     primary, secondary, shadow = (int(x) for x in counts.tolist())
     rays_per_frame = primary + secondary + shadow
 
+    # ---- the same scene at 7680x4320 (BASELINE.json configs[3]), sharded the same way: four times the rows per rank,
+    # so the shares of 8 ranks are as long as a 4K share of 2.  Timed like the main region, every rank takes part.
+    frame_8k = None
+    if args.workload == "4k" and not args.no_extras:
+        w8, h8 = WORKLOADS["8k"][:2]
+        r8 = ShardedRenderer(ctx, w8, h8, DEPTH, rank, world, torch.device("cuda", local_rank))
+        steps8 = max(5, args.steps // 4)
+        for _ in range(5):
+            r8.render(cam)
+        r8.finish()
+        barrier()
+        t8 = time.perf_counter()
+        for _ in range(steps8):
+            r8.render(cam)
+        r8.finish()
+        barrier()
+        el8 = time.perf_counter() - t8
+        s8 = make_ctx(stats=True)
+        f8 = Frame(w8, h8, DEPTH, rank, world)
+        b8 = torch.zeros(s8.frame_rows(f8) * w8 * 3, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        s8.render_device(cam, f8, b8.data_ptr(), renderer.stream.cuda_stream)
+        torch.cuda.synchronize()
+        st8 = s8.stats()
+        s8.close()
+        c8 = torch.tensor([st8.primary_rays + st8.secondary_rays, st8.shadow_rays, el8], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            ps = c8[:2].clone()
+            dist.all_reduce(ps)
+            tm = c8[2:].clone()
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            c8 = torch.cat([ps, tm])
+        ps8, sh8, el8 = c8.tolist()
+        ms8 = el8 / steps8 * 1e3
+        frame_8k = {"workload": WORKLOADS["8k"][4], "steps": steps8, "ms_per_step": round(ms8, 4),
+                    "value": round(ps8 / (ms8 * 1e-3) / 1e6, 2), "unit": "Mrays/s (primary+secondary)",
+                    "mrays_all": round((ps8 + sh8) / (ms8 * 1e-3) / 1e6, 2)}
+        del r8, b8
+
     # ---- dominant kernel: live HIP-event timing of k_render on its own stream (rank 0's share) ----
     roofline = None
     extra = {}
@@ -325,24 +418,27 @@ def main():
         kernel_ms = timed(lambda k: ctx.render_device(cam, fr, buf.data_ptr(), stream), n_launch)
         flops = algorithmic_flops(st, rows * WIDTH)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
-        # counters of the same kernel on the same frame, from the committed rocprofv3 passes
-        traffic, issue = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                prof = json.load(open(tpath)).get(args.workload, {})
-                traffic = prof.get("k_render_hbm_bytes_per_launch_n%d" % world)
-                wave_insts = prof.get("k_render_valu_wave_insts_per_launch_n%d" % world)
-                lane_insts = prof.get("k_render_valu_lane_insts_per_launch_n%d" % world)
-                if wave_insts and lane_insts:
-                    # one wave64 VALU instruction occupies its SIMD for 4 clocks; 1024 SIMDs; 64 lanes/CU/clk
-                    issue = {"valu_wave_insts_per_launch": int(wave_insts), "valu_lane_insts_per_launch": int(lane_insts),
-                             "simd_issue_frac": round(wave_insts * 4 / (N_SIMD * CLOCK_HZ * kernel_ms * 1e-3), 4),
-                             "lane_slot_frac": round(lane_insts / (N_SIMD * 16 * CLOCK_HZ * kernel_ms * 1e-3), 4),
-                             "mean_active_lanes": round(lane_insts / wave_insts, 1),
-                             "source": "%s (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU) / live kernel time" % prof.get("source", "profiles/traffic.json")}
-            except Exception:
-                traffic, issue = None, None
+        # counters of the same kernels on the same frames, from the rocprofv3 passes run at the start of this program
+        traffic, issue, hw = None, None, None
+        if counters and world == 1:
+            secs = kernel_ms * 1e-3
+            # gfx950: FETCH_SIZE (KB) tallies 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE (KB) as is
+            traffic = int(2 * counters.get("FETCH_SIZE", 0.0) * 1024 + counters.get("WRITE_SIZE", 0.0) * 1024)
+            wave_insts, lane_insts = counters.get("SQ_INSTS_VALU", 0.0), counters.get("SQ_THREAD_CYCLES_VALU", 0.0)
+            hw = {"source": "rocprofv3 --pmc over scripts/counter_frames.py %s (%d frames), run by this program before its timed region; "
+                            "sums over the render kernels of a frame" % (args.workload, counter_frames),
+                  "kernels": counters.get("kernels"),
+                  "FETCH_SIZE_kb": round(counters.get("FETCH_SIZE", 0.0), 1), "WRITE_SIZE_kb": round(counters.get("WRITE_SIZE", 0.0), 1),
+                  "framebuffer_bytes": rows * WIDTH * 3,
+                  "SQ_INSTS_VALU": int(wave_insts), "SQ_THREAD_CYCLES_VALU": int(lane_insts),
+                  "wait_inst_any_frac_of_wave_cycles": round(counters.get("SQ_WAIT_INST_ANY", 0.0) / max(counters.get("SQ_WAVE_CYCLES", 0.0), 1.0), 4)}
+            if wave_insts and lane_insts:
+                # one wave64 VALU instruction occupies its SIMD for 4 clocks; 1024 SIMDs; 16 lanes per SIMD and clock
+                issue = {"valu_wave_insts_per_launch": int(wave_insts), "valu_lane_insts_per_launch": int(lane_insts),
+                         "simd_issue_frac": round(wave_insts * 4 / (N_SIMD * CLOCK_HZ * secs), 4),
+                         "lane_slot_frac": round(lane_insts / (N_SIMD * 16 * CLOCK_HZ * secs), 4),
+                         "mean_active_lanes": round(lane_insts / wave_insts, 1),
+                         "source": "live counter passes (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU) / live kernel time"}
         # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
         roofline = {
@@ -351,12 +447,38 @@ def main():
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
                     "the reference bit for bit, so 1 flop/lane/clk = 39.3 TFLOP/s is the most such code can reach",
-            "valu_issue": issue,
+            "valu_issue": issue, "counters": hw,
             "hbm": {"algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gbs": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 1),
-                    "peak_gbs": PEAK_HBM_GBS, "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
+                    "peak_gbs": PEAK_HBM_GBS, "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                    "note": "bytes the walks ask for (64 B per node pair, 48 B per triangle, 3 B per texel and pixel); the caches serve "
+                            "most of them, `traffic` is what the counters saw between L2 and memory"},
         }
 
-        if not heavy:
+        # ---- the tolerance build of the same sources (librtx_hip_fast.so: contracted multiply-adds, hardware-rate
+        # division, square root and powf): same frame, its kernel time and how far its pixels are from the exact ones
+        if world == 1 and not args.no_extras and os.path.exists(HIP_FAST_LIB_PATH):
+            fctx = make_ctx(backend=hip_fast_backend())
+            fbuf = torch.zeros_like(buf)
+            torch.cuda.synchronize()
+            for _ in range(1 if heavy else 5):
+                fctx.render_device(cam, fr, fbuf.data_ptr(), stream)
+            fast_ms = timed(lambda k: fctx.render_device(cam, fr, fbuf.data_ptr(), stream), n_launch)
+            ctx.render_device(cam, fr, buf.data_ptr(), stream)
+            torch.cuda.synchronize()
+            fctx.close()
+            diff = (buf.view(-1, 3).to(torch.int16) - fbuf.view(-1, 3).to(torch.int16)).abs()
+            mse = float((diff.to(torch.float32) ** 2).mean().item())
+            fast_tf = flops / (fast_ms * 1e-3) / 1e12
+            roofline["tolerance_build"] = {
+                "library": "librtx_hip_fast.so (-ffp-contract=fast, 2.5-ulp division and square root, powf as exp2(y log2 x))",
+                "kernel_ms": round(fast_ms, 4), "achieved": round(fast_tf, 3), "frac": round(fast_tf / PEAK_FP32_VALU_TFLOPS, 5),
+                "psnr_db_vs_exact": round(10 * np.log10(255.0 ** 2 / mse), 2) if mse > 0 else None,
+                "pixels_within_1_of_255": round(float((diff.max(dim=1).values <= 1).to(torch.float32).mean().item()), 6),
+                "pixels_differing": int((diff.max(dim=1).values > 0).sum().item()),
+            }
+            del fbuf, diff
+
+        if not heavy and not args.no_extras:
             # ---- what the steady state leaves out (this rank's share; device time by HIP events) ----
             # a single frame of a new view: fresh contexts, the very first frame each (tile list from projected boxes)
             firsts = []
@@ -413,6 +535,8 @@ def main():
             "roofline": roofline,
         }
         out.update(extra)
+        if frame_8k is not None:
+            out["frame_8k"] = frame_8k
         if world == 1 and not args.no_cpu_baseline and (WIDTH, HEIGHT) == (3840, 2160) and not stress:
             gpu_frame = renderer.render(cam)[0]
             renderer.finish()
