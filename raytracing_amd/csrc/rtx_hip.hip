@@ -39,6 +39,9 @@ struct DevCamera {
 struct DevFrame {
     int width, height, depth, row_first, row_step, rows;
     int spp;  // RTX_OPT_SPP: 1 or 4
+    // k_render's LDS per lane: `stack_entries` dwords of traversal stack (as deep as the scene's trees), then the heads of
+    // `lds_frames` frames of the recursion, six dwords each
+    int stack_entries, lds_frames;
 };
 
 // src/Scene.cpp:217-220; (dx, dy) = offset of the sample from the pixel centre, 0 in the reference
@@ -258,7 +261,7 @@ struct PixelJob {
 // (include/bitmap_image.hpp:207-209) go to `bgr` (the wave's tile buffer in LDS).
 template <bool STATS, bool WIDE>
 __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, PixelJob job,
-                                           PathState &st, Frame *frames, bool active, const int quad_j, unsigned char *bgr, int *stack,
+                                           PathState &st, FrameStack &frames, bool active, const int quad_j, unsigned char *bgr, int *stack,
                                            LaneCounters<STATS> &lc) {
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     int sample = 0;
@@ -303,7 +306,7 @@ RTX_DEV float sampleDy(int k) { return k == 0 ? 0.375f : (k == 1 ? 0.125f : (k =
 // sample order afterwards.
 template <bool STATS>
 __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, int x0, int y0,
-                                              PathState &st, Frame *frames, float *samples, unsigned char *tile_bgr, int *stack,
+                                              PathState &st, FrameStack &frames, float *samples, unsigned char *tile_bgr, int *stack,
                                               LaneCounters<STATS> &lc) {
     const unsigned lane = threadIdx.x & 63u;
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
@@ -360,19 +363,21 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
     bgr[0] = toByte(sum.z), bgr[1] = toByte(sum.y), bgr[2] = toByte(sum.x);
 }
 
+// k_render's per-lane LDS (sized by the launch): the traversal stack, then the frame heads; dword k of lane t at [k * kBlock + t]
+extern __shared__ int s_lane_lds[];
+
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
                                                    const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned batch_from_arg, unsigned *heads, unsigned *heads_next,
                                                    unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
                                                    Counters *counters) {
-    __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
     __shared__ float s_samples[WIDE ? kBlock / 64 : 1][WIDE ? 4 * 64 * 3 : 1];  // tracePathPool: colours per sample and pixel
     loadSmallScene(q, s);
     __syncthreads();
-    int *stack = s_stack + threadIdx.x;
+    int *stack = s_lane_lds + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     // the queue heads come in two sets: this launch counts in one and clears the other for the next
     // launch of the context (launches of a context follow one another), which saves a fill per frame
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
     LaneCounters<STATS> lc;
     PathState st;
-    Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
+    FrameSpill spill;  // the heads of the first frames in LDS, what is indexed dynamically beyond them in scratch memory
+    FrameStack frames = frameStack(spill, reinterpret_cast<float *>(s_lane_lds + fr.stack_entries * kBlock + threadIdx.x), fr.lds_frames, kBlock);
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
     // Taking a tile is two dependent round trips to memory (the head counter, then the list entry), a
     // few microseconds during which the wave does nothing -- as long as a cheap tile takes to trace.  The
@@ -727,6 +733,8 @@ struct rtx_ctx {
     int pipeline = 2;                       // RTX_OPT_PIPELINE
     WfMem wf;
     int wf_stack_entries = kStackDepth;     // LDS traversal stack entries per lane of the pipeline's kernels
+    int stack_entries = kStackDepth;        // ... and of k_render
+    int lds_frame_slots[4] = {0, 0, 0, 0};  // frame heads of a lane that k_render keeps in LDS, per variant
     int sphere_bvh_depth = 0;
     int wf_blocks[3][4] = {};               // resident blocks of k_wf_trace / k_wf_shadow [STATS + 2 * WIDE], k_wf_shade [STATS]
     size_t wf_budget = (size_t)16 << 30;    // bytes the pipeline's arrays may take
@@ -937,15 +945,31 @@ using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned,
                               unsigned *, unsigned *, unsigned char *, Counters *);
 const RenderKernel kRenderKernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
 
+// bytes of k_render's per-lane LDS
+constexpr size_t renderLds(int stack_entries, int frame_slots) { return (size_t)(stack_entries + 6 * frame_slots) * kBlock * sizeof(int); }
+
 // Blocks of every k_render variant that are resident at once (the kernel is a loop over tiles; more
 // blocks would only queue).  Worked out once, in rtx_commit.
 int residentBlocks(rtx_ctx *c) {
     hipDeviceProp_t prop;
     HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
+    // traversal stacks as deep as the scene's trees need (one entry more: the walk stores before it counts)
+    c->stack_entries = std::max(1, std::min(kStackDepth, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
     for (int variant = 0; variant < 4; ++variant) {
         int per_cu = 0;
-        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kRenderKernels[variant], kBlock, 0));
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kRenderKernels[variant], kBlock, renderLds(c->stack_entries, 0)));
         c->resident_blocks[variant] = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
+        // frame heads go to LDS as far as that costs no resident block
+        int slots = 0;
+        while (slots < kMaxDepth - 1) {
+            int with = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, kRenderKernels[variant], kBlock, renderLds(c->stack_entries, slots + 1)) != hipSuccess ||
+                with < per_cu)
+                break;
+            ++slots;
+        }
+        (void)hipGetLastError();
+        c->lds_frame_slots[variant] = slots;
     }
     return RTX_OK;
 }
@@ -957,7 +981,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
                  SchedState &ss, bool feedback) {
     const int rows = rtx_frame_rows(f);
     if (rows == 0) return RTX_OK;
-    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows, c->spp};
+    DevFrame fr{f->width, f->height, f->depth, f->row_first, f->row_step, rows, c->spp, c->stack_entries, 0};
     const int tiles_x = (f->width + 7) / 8, tiles_y = (rows + 7) / 8;
     const long long n_tiles = (long long)tiles_x * tiles_y;
     if (n_tiles > (long long)kTileMask || (size_t)n_tiles > m.cap) return fail(RTX_E_LIMIT, "frame too large for one launch");
@@ -983,6 +1007,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     const bool wide = c->big_spheres || c->spp > 1 || c->long_lists;
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     const int resident = c->resident_blocks[variant];
+    fr.lds_frames = std::max(0, std::min(f->depth - 1, c->lds_frame_slots[variant]));  // a frame of depth d has at most d - 1 nodes waiting
     const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
@@ -1009,7 +1034,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         ss.by_cost_key.valid = ss.static_key.valid = false;
         (by_cost ? ss.by_cost_key : ss.static_key).set(cam, f);
     }
-    hipLaunchKernelGGL(kRenderKernels[variant], dim3(blocks), dim3(kBlock), 0, stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
+    hipLaunchKernelGGL(kRenderKernels[variant], dim3(blocks), dim3(kBlock), renderLds(fr.stack_entries, fr.lds_frames), stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
                        order, list_hdr, batch_from, heads, heads_next, m.cost, d_out, c->d_counters);
     HIP_OR_FAIL(hipGetLastError());
     ss.heads_flip = !ss.heads_flip;  // only now: a launch that failed has cleared nothing

@@ -541,12 +541,67 @@ RTX_DEV V3 skyColor(const DevScene &s, V3 dir) {
 // With pruning on, a child whose weight is exactly 0 is not traced and its (exactly zero)
 // contribution not added; x + 0*c == x for every finite c, so the result is unchanged.
 // ---------------------------------------------------------------------------------------------
-struct Frame {
-    V3 acc;          // partial sum so far
+struct FrameHead {
+    V3 acc;  // partial sum so far
     float a2, a3;
-    V3 rorig, rdir;  // pending refract ray
-    int state;       // bit0: waiting for reflect, bit1: refract still to do, bit2: waiting for refract, bits 8..: depth of this node
+    int state;  // bit0: waiting for reflect, bit1: refract still to do, bit2: waiting for refract, bits 8..: depth of this node
 };
+struct FrameRay {
+    V3 orig, dir;  // pending refract ray (only nodes with both children have one)
+};
+
+// The frames of one lane.  The heads of the first `lds_slots` frames live in LDS -- field k of frame j at
+// lds[(6 * j + k) * lds_stride], consecutive lanes in consecutive dwords -- the heads beyond them and the
+// pending refract rays in the lane's scratch memory (dynamically indexed arrays cannot stay in registers).
+// A kernel that has no LDS to spare passes lds_slots = 0.
+struct FrameSpill {
+    FrameHead heads[kMaxDepth];
+    FrameRay rays[kMaxDepth];
+};
+struct FrameStack {
+    float *lds;
+    int lds_slots, lds_stride;
+    FrameHead *heads;
+    FrameRay *rays;
+};
+
+RTX_DEV FrameStack frameStack(FrameSpill &spill, float *lds = nullptr, int lds_slots = 0, int lds_stride = 0) {
+    return FrameStack{lds, lds_slots, lds_stride, spill.heads, spill.rays};
+}
+
+RTX_DEV FrameHead frameHead(const FrameStack &fs, int j) {
+    if (j < fs.lds_slots) {
+        const float *p = fs.lds + 6 * j * fs.lds_stride;
+        FrameHead f;
+        f.acc = v3(p[0], p[fs.lds_stride], p[2 * fs.lds_stride]);
+        f.a2 = p[3 * fs.lds_stride], f.a3 = p[4 * fs.lds_stride];
+        f.state = __float_as_int(p[5 * fs.lds_stride]);
+        return f;
+    }
+    return fs.heads[j];
+}
+
+RTX_DEV void frameSetHead(FrameStack &fs, int j, const FrameHead &f) {
+    if (j < fs.lds_slots) {
+        float *p = fs.lds + 6 * j * fs.lds_stride;
+        p[0] = f.acc.x, p[fs.lds_stride] = f.acc.y, p[2 * fs.lds_stride] = f.acc.z;
+        p[3 * fs.lds_stride] = f.a2, p[4 * fs.lds_stride] = f.a3;
+        p[5 * fs.lds_stride] = __int_as_float(f.state);
+    } else {
+        fs.heads[j] = f;
+    }
+}
+
+// after the reflect child: only the partial sum and the state have changed
+RTX_DEV void frameSetSum(FrameStack &fs, int j, const FrameHead &f) {
+    if (j < fs.lds_slots) {
+        float *p = fs.lds + 6 * j * fs.lds_stride;
+        p[0] = f.acc.x, p[fs.lds_stride] = f.acc.y, p[2 * fs.lds_stride] = f.acc.z;
+        p[5 * fs.lds_stride] = __int_as_float(f.state);
+    } else {
+        fs.heads[j].acc = f.acc, fs.heads[j].state = f.state;
+    }
+}
 
 struct PathState {
     V3 orig, dir;   // the ray to cast next
@@ -629,9 +684,8 @@ RTX_DEV LightAim aimLight(const DevScene &s, const SmallScene &q, const PathStat
 
 // the shadow ray towards an aimed light becomes the pending ray, :65-70
 RTX_DEV void pathAimShadowRay(const DevScene &s, PathState &st, const LightAim &a) {
-    const V3 off = st.N * s.fprec;
     st.ndl = a.ndl;
-    st.orig = __builtin_signbit(a.ndl) ? st.point - off : st.point + off;
+    st.orig = st.point + st.N * (__builtin_signbit(a.ndl) ? -s.fprec : s.fprec);  // (= point - N * fprec bit for bit on the far side)
     st.dir = a.dir;
     st.lightDist = distance(a.pos, st.point);
     // A hit nearer than this decides the reference's test for certain: the closest hit is then at
@@ -664,7 +718,7 @@ RTX_DEV int quadBroadcast(int v) {
 // was not cast) and sets up the next one.  Returns true when the whole tree is done; `color` is
 // then the value traceRay would have returned.
 template <bool STATS, bool WIDE = false>
-RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, Frame *frames, bool hit, const Hit &h, float md,
+RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, FrameStack &frames, bool hit, const Hit &h, float md,
                          int quad_j, V3 &color, LaneCounters<STATS> &lc) {
     const bool shadow = st.light >= 0;
     const bool count = quad_j <= 0;  // statistics: once per pixel
@@ -741,7 +795,9 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         if (!doRefl && !doRefr) {
             color = base;
         } else {
-            const V3 positiveOrig = st.point + st.N * s.fprec, negativeOrig = st.point - st.N * s.fprec;
+            // the child's origin: the point moved along N to the side the child leaves on.  point - N * e is
+            // point + N * (-e) bit for bit, which saves choosing between two vectors
+            const auto childOrigin = [&](V3 d) { return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec); };
             V3 reflD = v3(0, 0, 0), refrD = v3(0, 0, 0);
             if (doRefl) reflD = normalize(reflect(dir, st.N));
             if (doRefr) refrD = normalize(refractDir(dir, st.N, m.refractive));
@@ -759,23 +815,23 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                 }
                 color = c;
             } else {
-                Frame f;
+                FrameHead f;
                 f.acc = base;
                 f.a2 = m.a2, f.a3 = m.a3;
                 f.state = (doRefl ? 1 : 0) | (doRefr ? 2 : 0) | (depth << 8);
-                f.rdir = refrD;
-                f.rorig = __builtin_signbit(dot(refrD, st.N)) ? negativeOrig : positiveOrig;
+                V3 refrO = v3(0, 0, 0);
+                if (doRefr) refrO = childOrigin(refrD);
                 if (doRefl) {
-                    st.orig = __builtin_signbit(dot(reflD, st.N)) ? negativeOrig : positiveOrig;
+                    st.orig = childOrigin(reflD);
                     st.dir = reflD;
                 } else {
-                    st.orig = f.rorig, st.dir = f.rdir;
+                    st.orig = refrO, st.dir = refrD;
                     f.state = (f.state & ~2) | 4;
                 }
+                const int j = st.sp++;
+                frameSetHead(frames, j, f);
                 // the pending refract ray is only stored when there is one (most nodes have the reflect child alone)
-                Frame &slot = frames[st.sp++];
-                slot.acc = f.acc, slot.a2 = f.a2, slot.a3 = f.a3, slot.state = f.state;
-                if (f.state & 2) slot.rorig = f.rorig, slot.rdir = f.rdir;
+                if (f.state & 2) frames.rays[j].orig = refrO, frames.rays[j].dir = refrD;
                 st.depth = depth - 1;
                 return false;
             }
@@ -783,22 +839,22 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
     }
     // ---- return `color` to the waiting frames ----
     while (st.sp > 0) {
-        Frame &f = frames[st.sp - 1];
+        const int j = st.sp - 1;
+        FrameHead f = frameHead(frames, j);
         if (f.state & 1) {  // reflect child returned
             f.acc = f.acc + color * f.a2;
-            f.state &= ~1;
             if (f.state & 2) {  // now the refract child
-                f.state = (f.state & ~2) | 4;
-                st.orig = f.rorig, st.dir = f.rdir;
+                f.state = (f.state & ~3) | 4;
+                frameSetSum(frames, j, f);
+                st.orig = frames.rays[j].orig, st.dir = frames.rays[j].dir;
                 st.depth = (f.state >> 8) - 1;
                 return false;
             }
             color = f.acc;
-            --st.sp;
         } else {  // refract child returned
             color = f.acc + color * f.a3;
-            --st.sp;
         }
+        --st.sp;
     }
     return true;
 }
@@ -806,7 +862,8 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
 template <bool STATS, bool WIDE = false>
 RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
     PathState st;
-    Frame frames[kMaxDepth];  // dynamically indexed: lives in scratch memory, the rest of the state in registers
+    FrameSpill spill;  // all frames in scratch memory here, the rest of the state in registers
+    FrameStack frames = frameStack(spill);
     pathStart(st, orig, dir, depth);
     V3 color = v3(0, 0, 0);
     for (;;) {

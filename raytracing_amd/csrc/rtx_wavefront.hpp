@@ -378,14 +378,14 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
             const V3 base = v3(m.dr * st.Ld * m.a0, m.dg * st.Ld * m.a0, m.db * st.Ld * m.a0) + v3(st.Ls * m.a1, st.Ls * m.a1, st.Ls * m.a1);
             doRefl = !s.prune || m.a2 != 0.0f;
             doRefr = !s.prune || m.a3 != 0.0f;
-            const V3 positiveOrig = st.point + st.N * s.fprec, negativeOrig = st.point - st.N * s.fprec;
+            const auto childOrigin = [&](V3 d) { return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec); };
             if (doRefl) {
                 reflD = normalize(reflect(dir, st.N));
-                reflO = __builtin_signbit(dot(reflD, st.N)) ? negativeOrig : positiveOrig;
+                reflO = childOrigin(reflD);
             }
             if (doRefr) {
                 refrD = normalize(refractDir(dir, st.N, m.refractive));
-                refrO = __builtin_signbit(dot(refrD, st.N)) ? negativeOrig : positiveOrig;
+                refrO = childOrigin(refrD);
             }
             if (depth == 1) {
                 // the children have depth 0: the sky colour of their direction, in place (:87-88)
