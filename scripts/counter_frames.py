@@ -1,6 +1,7 @@
 """Renders FRAMES frames of one bench workload through the C ABI and nothing else (no torch: starts in a second).
 bench.py runs it under `rocprofv3 --pmc ...`, one counter group per run, and reads the counters of the render
-kernels from the CSV.  usage: python3 scripts/counter_frames.py <workload> [frames] [library]"""
+kernels from the CSV.  usage: python3 scripts/counter_frames.py <workload> [frames] [library]
+(RTX_COUNTER_OPTS="8=0,7=0" in the environment sets options of the context: id=value pairs of rtx_set_option)"""
 import os
 import sys
 
@@ -20,6 +21,8 @@ if name.startswith("stress"):
     scenes.load_stress_scene(ctx, H, water, sky)
 else:
     ctx.load_default_scene(water, sky, mask=mask)
+for pair in filter(None, os.environ.get("RTX_COUNTER_OPTS", "").split(",")):
+    ctx.set_option(int(pair.split("=")[0]), float(pair.split("=")[1]))
 ctx.commit()
 cam = H.default_camera()
 for _ in range(frames):
