@@ -476,6 +476,10 @@ def main():
                 "pixels_within_1_of_255": round(float((diff.max(dim=1).values <= 1).to(torch.float32).mean().item()), 6),
                 "pixels_differing": int((diff.max(dim=1).values > 0).sum().item()),
             }
+            tb = roofline["tolerance_build"]
+            # the tolerance of the path: PSNR >= 50 dB and >= 99.9 % of the pixels within 1/255.  (Scenes whose pixels the
+            # reference's sphere test decides by rounding noise -- thousands of small far spheres, the stress scene -- are outside it.)
+            tb["meets_tolerance"] = bool((tb["psnr_db_vs_exact"] is None or tb["psnr_db_vs_exact"] >= 50.0) and tb["pixels_within_1_of_255"] >= 0.999)
             del fbuf, diff
 
         if not heavy and not args.no_extras:
