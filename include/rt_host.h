@@ -59,7 +59,8 @@ int rt_scene_load_default_tex(rtx_ctx *ctx, const char *bunny_obj_path, unsigned
 int rt_save_bmp(const unsigned char *bgr, int width, int height, const char *path);
 
 /* replaces: main + parseArgs (src/rt.cpp:7-49) with the same flags (-out, -scene, -threads; all
- * three or none) plus optional -w, -h, -depth, -envmap, -resources, -device.  Returns the exit code. */
+ * three or none) plus optional -w, -h, -depth, -envmap, -resources, -device, -gpus (the frame's rows
+ * interleaved over that many GPUs, starting at -device: rtx_group_*).  Returns the exit code. */
 int rt_main(int argc, char **argv);
 
 const char *rt_host_last_error(void);
