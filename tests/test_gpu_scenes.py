@@ -419,6 +419,24 @@ def test_api_errors(hip, textures):
     assert ctx.render(hip.default_camera(), 16, 16, 4, row_first=16).shape == (0, 16, 3)  # no rows owned
 
 
+@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("depth", [6, 8])
+def test_deepest_recursion_equals_the_oracle(hip, oracle_backend, textures, depth, pipeline):
+    """Up to RTX_MAX_DEPTH levels of reflection and refraction: more waiting nodes per pixel than the one-kernel
+    path keeps in LDS (the rest, and the pending refract rays of glass, live in per-lane scratch memory)."""
+    from raytracing_amd.rtx import OPT_PIPELINE
+    frames = []
+    for b in (oracle_backend, hip):
+        ctx = make_default_context(b, textures, sky="map.jpg", options=[(OPT_PIPELINE, pipeline)] if b is hip else [])
+        cam = b.default_camera()
+        for _ in range(1 if b is oracle_backend else 3):  # static order, cost order, quad mode
+            frames.append(ctx.render(cam, 200, 150, depth))
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+    shallow = make_default_context(hip, textures, sky="map.jpg").render(hip.default_camera(), 200, 150, 4)
+    assert not np.array_equal(shallow, frames[0])  # the extra levels do reach pixels
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_row_interleaved_shares_reassemble(hip, textures, world):
     """Logical ranks on one device: every rank's compact rows equal the rows of the whole frame."""
