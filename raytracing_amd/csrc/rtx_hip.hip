@@ -1189,56 +1189,22 @@ int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsig
             return dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(chunks, (unsigned long long)resident)));
         };
         const size_t lds = (size_t)c->wf_stack_entries * kBlock * sizeof(int);
-        // RTX_WF_TIMING=1: an event after every launch, the elapsed times printed when the frame is done (diagnostics)
-        static const bool timing = getenv("RTX_WF_TIMING") != nullptr;
-        std::vector<std::pair<const char *, hipEvent_t>> marks;
-        static const bool marks_only = getenv("RTX_WF_MARKS") != nullptr;
-        auto mark = [&](const char *what) {
-            if (marks_only) {
-                (void)hipEventRecord(c->ev1, stream);
-                return;
-            }
-            if (!timing) return;
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
-            (void)hipEventRecord(e, stream);
-            marks.emplace_back(what, e);
-        };
-        mark("pre");
         hipLaunchKernelGGL(k_wf_clear, dim3(4), dim3(kBlock), 0, stream, w.counters, std::min(D, kWfLevels));
-        mark("clear");
         for (int l = 0; l < (D > 0 ? D : 1); ++l) {
             hipLaunchKernelGGL(kWfTrace[variant], grid(c->wf_blocks[0][variant], samples << l), dim3(kBlock), lds, stream, s, dcam, fr, strip,
                                wfArgs(w, l, 0), c->d_counters);
-            mark("trace");
             if (D == 0) break;
             hipLaunchKernelGGL(kWfShadow[variant], grid(c->wf_blocks[1][variant], (samples << l) * (unsigned)std::max(1, s.n_lights)), dim3(kBlock), lds,
                                stream, s, wfArgs(w, l, 1), c->d_counters);
-            mark("shadow");
             hipLaunchKernelGGL(kWfShade[variant], grid(c->wf_blocks[2][variant], samples << l), dim3(kBlock), 0, stream, s, fr,
                                wfArgs(w, l, 2), c->d_counters);
-            mark("shade");
         }
         for (int l = D - 2; l >= 0; --l) {
             hipLaunchKernelGGL(k_wf_resolve, grid(c->wf_blocks[2][0] * 2, samples << l), dim3(kBlock), 0, stream, wfArgs(w, l, 3));
-            mark("resolve");
         }
         hipLaunchKernelGGL(k_wf_pixels, grid(c->wf_blocks[2][0] * 2, (unsigned long long)strip.n_tiles * 64u), dim3(kBlock), 0, stream, fr, strip,
                            w.samples, d_out);
         HIP_OR_FAIL(hipGetLastError());
-        mark("pixels");
-        if (timing) {
-            (void)hipStreamSynchronize(stream);
-            float whole = 0;
-            (void)hipEventElapsedTime(&whole, c->ev0, marks.back().second);
-            fprintf(stderr, "  ev0 -> last mark %8.1f us\n", whole * 1e3f);
-            for (size_t k = 1; k < marks.size(); ++k) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, marks[k - 1].second, marks[k].second);
-                fprintf(stderr, "  %-8s %8.1f us\n", marks[k].first, ms * 1e3f);
-            }
-            for (auto &m : marks) (void)hipEventDestroy(m.second);
-        }
     }
     HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
     c->timed = true;
