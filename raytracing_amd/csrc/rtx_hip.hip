@@ -960,12 +960,14 @@ int residentBlocks(rtx_ctx *c) {
         HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kRenderKernels[variant], kBlock, renderLds(c->stack_entries, 0)));
         c->resident_blocks[variant] = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
         // frame heads go to LDS as far as that costs no resident block
+        hipFuncAttributes attr;
+        HIP_OR_FAIL(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kRenderKernels[variant])));
         int slots = 0;
         while (slots < kMaxDepth - 1) {
             int with = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, kRenderKernels[variant], kBlock, renderLds(c->stack_entries, slots + 1)) != hipSuccess ||
-                with < per_cu)
-                break;
+            const size_t lds = renderLds(c->stack_entries, slots + 1);
+            if (attr.sharedSizeBytes + lds > 64u * 1024u) break;  // a workgroup's LDS without opting in to more
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, kRenderKernels[variant], kBlock, lds) != hipSuccess || with < per_cu) break;
             ++slots;
         }
         (void)hipGetLastError();
