@@ -142,6 +142,12 @@ struct SmallScene {
     float tris[kMaxSmallPrims * 9];
     float boxes[kMaxSmallPrims * 6];
     int sphere_mat[kMaxSmallPrims], tri_mat[kMaxSmallPrims], box_mat[kMaxSmallPrims];
+    // Constants of the scene that every ray looks at (copies of DevScene's): as kernel arguments they would sit in
+    // scalar registers for the whole kernel, which has too few of those (the overflow is parked in vector-register
+    // lanes and fetched back with a vector instruction per use); from here they cost a broadcast read.
+    float sphere_bounds[6], tri_bounds[6], box_bounds[6], object_bounds[6];
+    float island_rect[4];
+    float light_green[3], dark_green[3];
     RefMathTables math;  // powf tables (rtx_refmath.hpp), indexed per lane
 };
 
@@ -164,6 +170,10 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
     copy(q.boxes, s.boxes, staged(s.n_boxes, kMaxSmallPrims) * 6);
     copy(q.box_mat, s.box_mat, staged(s.n_boxes, kMaxSmallPrims));
     copy(&q.math, &kRefMathTables, (int)(sizeof(RefMathTables) / 4));
+    copy(q.sphere_bounds, s.sphere_bounds, 6), copy(q.tri_bounds, s.tri_bounds, 6), copy(q.box_bounds, s.box_bounds, 6);
+    copy(q.object_bounds, s.object_bounds, 6);
+    copy(q.island_rect, s.island_rect, 4);
+    copy(q.light_green, s.light_green, 3), copy(q.dark_green, s.dark_green, 3);
 }
 
 // List entry i: from the staging while it reaches, from global memory beyond.  Only the general build of the

@@ -317,8 +317,8 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
             // object_bounds holds the spheres' geometric boxes: the gate needs the same per-ray slack as the walk
             const float reach = sphereReach(s, orig, t_exit);
             const float delta = kSphereSlack * (reach + s.sphere_rmax);
-            const float lo[3] = {s.object_bounds[0] - delta, s.object_bounds[1] - delta, s.object_bounds[2] - delta};
-            const float hi[3] = {s.object_bounds[3] + delta, s.object_bounds[4] + delta, s.object_bounds[5] + delta};
+            const float lo[3] = {q.object_bounds[0] - delta, q.object_bounds[1] - delta, q.object_bounds[2] - delta};
+            const float hi[3] = {q.object_bounds[3] + delta, q.object_bounds[4] + delta, q.object_bounds[5] + delta};
             if (!slabMaybe(lo, hi, orig, inv)) return false;
             sphereWalk<STATS>(s, orig, dir, inv, reach, t_exit, minDist, index, stack, stride, lc);
             if (index >= 0) kind = 1;
@@ -329,10 +329,10 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     // launch the host sizes object_bounds and sphere_bounds with the slack that the rounding of
     // Sphere::rayIntersect calls for at the largest distance a ray of that launch can start from -- see
     // sphereWalk and sphereGateBounds -- so the two filters never reject a ray whose sphere test would pass.)
-    if (!walked && !slabMaybe(s.object_bounds, s.object_bounds + 3, orig, inv)) return false;
+    if (!walked && !slabMaybe(q.object_bounds, q.object_bounds + 3, orig, inv)) return false;
 
     // spheresIntersect, src/SceneObjects.cpp:289-302
-    if (!walked && s.n_spheres > 0 && slabMaybe(s.sphere_bounds, s.sphere_bounds + 3, orig, inv)) {
+    if (!walked && s.n_spheres > 0 && slabMaybe(q.sphere_bounds, q.sphere_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_SPHERE_TESTS, s.n_spheres);
         for (int i = 0; i < s.n_spheres; ++i) {
             const float4 sp = q.spheres[i];
@@ -344,7 +344,7 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
         }
     }
     // trianglesIntersect, :304-317
-    if (s.n_tris > 0 && !(minDist < t_exit) && slabMaybe(s.tri_bounds, s.tri_bounds + 3, orig, inv)) {
+    if (s.n_tris > 0 && !(minDist < t_exit) && slabMaybe(q.tri_bounds, q.tri_bounds + 3, orig, inv)) {
         RTX_COUNT_N(CNT_LOOSE_TRI_TESTS, s.n_tris);
         auto test = [&](const float *t, int i) {
             const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
@@ -362,7 +362,7 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
         }
     }
     // cubesIntersect, :382-397
-    if (s.n_boxes > 0 && !(minDist < t_exit) && slabMaybe(s.box_bounds, s.box_bounds + 3, orig, inv)) {
+    if (s.n_boxes > 0 && !(minDist < t_exit) && slabMaybe(q.box_bounds, q.box_bounds + 3, orig, inv)) {
         auto test = [&](const float *b, int i) {
             const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
             if (!slabMaybe(lo, hi, orig, inv)) return;
@@ -419,7 +419,7 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
             RTX_COUNT_N(CNT_ISLAND_TESTS, s.n_islands);
             const V3 pt = orig + dir * dist;
             // the rectangle around all islands first (padded; the exact conditions follow per island)
-            const bool near_islands = pt.x > s.island_rect[0] && pt.x < s.island_rect[1] && pt.z > s.island_rect[2] && pt.z < s.island_rect[3];
+            const bool near_islands = pt.x > q.island_rect[0] && pt.x < q.island_rect[1] && pt.z > q.island_rect[2] && pt.z < q.island_rect[3];
             for (int i = 0; near_islands && i < s.n_islands; ++i) {
                 const float4 is = islandAt<WIDE>(s, q, i);  // cx, cz, a, b
                 // the bounding-rectangle conditions come first in the reference's && chain as well; the
@@ -490,8 +490,8 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     } else if (kind == 6) {
         // checker and dots: src/SceneObjects.cpp:409-415
         const int parity = truncToInt(h.point.x + h.point.z) & 1;
-        const float *c0 = parity ? s.light_green : s.dark_green;
-        const float *c1 = parity ? s.dark_green : s.light_green;
+        const float *c0 = parity ? q.light_green : q.dark_green;
+        const float *c1 = parity ? q.dark_green : q.light_green;
         float x = h.point.x, fx = roundf(h.point.x);
         float z = ceilf(h.point.x + h.point.z) - fx - 0.5f;
         const float rad = 0.15f;
