@@ -17,6 +17,12 @@ namespace rtx {
 
 #define RTX_DEV __device__ __forceinline__
 
+// Everything in this file is geometry -- what decides which texel, which side of a shadow's edge, which way a mirrored
+// ray goes -- and is never contracted, in the tolerance build either (its compiler flags allow fused multiply-adds; the
+// pragma below takes that back until the end of the file).  A direction that is off by an ulp looks up another texel of
+// the environment map in a mirror ball, and the neighbouring texel differs by far more than 1/255.
+#pragma clang fp contract(off)
+
 constexpr float kEps = 1.1920928955078125e-07f;   // std::numeric_limits<float>::epsilon()
 constexpr float kFltMax = 3.4028234663852886e+38f;
 constexpr float kFltMin = 1.1754943508222875e-38f;  // numeric_limits<float>::min()
@@ -330,6 +336,9 @@ RTX_DEV V3 boxNormal(const float lo[3], const float hi[3], V3 hit) {
     return normalize(v3((float)iv1, (float)iv2, (float)iv3));
 }
 
+// the direction of a mirrored ray, src/Scene.cpp:97
+RTX_DEV V3 reflectDir(V3 I, V3 N) { return normalize(reflect(I, N)); }
+
 // glm::intersectRayPlane for the plane y = plane_y with normal (0,1,0)
 // (include/glm/gtx/intersect.inl:6-26).  dot(dir, n) = dir.x*0 + dir.y*1 + dir.z*0 equals dir.y
 // and dot(p0 - orig, n) equals plane_y - orig.y whenever the other components are finite (adding
@@ -368,5 +377,9 @@ RTX_DEV V3 refractDir(V3 I, V3 N, float etat) {
     if (k < 0) return v3(1, 0, 0);
     return I * eta + N * (eta * cosi - sqrtf(k));
 }
+
+#ifdef RTX_FAST_MATH
+#pragma clang fp contract(fast)  // the tolerance build: shading arithmetic (what follows this file) may fuse
+#endif
 
 }  // namespace rtx

@@ -46,6 +46,8 @@ struct DevFrame {
 
 // src/Scene.cpp:217-220; (dx, dy) = offset of the sample from the pixel centre, 0 in the reference
 RTX_DEV V3 primaryDir(const DevCamera &cam, int width, int height, int i, int j, float dx = 0.0f, float dy = 0.0f) {
+    // (also in the tolerance build, which contracts elsewhere: every pixel's whole tree hangs on this direction)
+#pragma clang fp contract(off)
     float x = (((float)j + 0.5f) + dx) - (float)width / 2.0f;
     float y = -(((float)i + 0.5f) + dy) + (float)height / 2.0f;
     float z = (float)(-height) / (2.0f * cam.tan_half_fov);
@@ -367,16 +369,40 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
 extern __shared__ int s_lane_lds[];
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam, DevFrame fr, unsigned tiles_x, unsigned n_tiles,
-                                                   const unsigned *__restrict__ order, const unsigned *__restrict__ n_entries_dev,
-                                                   unsigned batch_from_arg, unsigned *heads, unsigned *heads_next,
-                                                   unsigned *__restrict__ tile_cost, unsigned char *__restrict__ out,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam_arg, DevFrame fr_arg, unsigned tiles_x_arg, unsigned n_tiles,
+                                                   const unsigned *__restrict__ order_arg, const unsigned *__restrict__ n_entries_dev,
+                                                   unsigned batch_from_arg, unsigned *heads_arg, unsigned *heads_next,
+                                                   unsigned *__restrict__ tile_cost_arg, unsigned char *__restrict__ out_arg,
                                                    Counters *counters) {
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
     __shared__ float s_samples[WIDE ? kBlock / 64 : 1][WIDE ? 4 * 64 * 3 : 1];  // tracePathPool: colours per sample and pixel
+    // What only the code between two tiles looks at (camera, frame description, list and output pointers) is read from
+    // LDS there: as kernel arguments these forty-odd dwords would sit in scalar registers through the whole path loop,
+    // which has too few of those (the overflow is parked in vector-register lanes and fetched back with a vector
+    // instruction per use).
+    struct TileArgs {
+        DevCamera cam;
+        DevFrame fr;
+        unsigned tiles_x;
+        const unsigned *order;
+        unsigned *heads, *tile_cost;
+        unsigned char *out;
+    };
+    __shared__ TileArgs ta;
+    if (threadIdx.x == 0) {
+        ta.cam = cam_arg, ta.fr = fr_arg, ta.tiles_x = tiles_x_arg, ta.order = order_arg, ta.heads = heads_arg, ta.tile_cost = tile_cost_arg;
+        ta.out = out_arg;
+    }
     loadSmallScene(q, s);
     __syncthreads();
+    const DevCamera &cam = ta.cam;
+    const DevFrame &fr = ta.fr;
+    const unsigned &tiles_x = ta.tiles_x;
+    const unsigned *const &order = ta.order;
+    unsigned *const &heads = ta.heads;
+    unsigned *const &tile_cost = ta.tile_cost;
+    unsigned char *const &out = ta.out;
     int *stack = s_lane_lds + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     // the queue heads come in two sets: this launch counts in one and clears the other for the next
@@ -395,7 +421,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     LaneCounters<STATS> lc;
     PathState st;
     FrameSpill spill;  // the heads of the first frames in LDS, what is indexed dynamically beyond them in scratch memory
-    FrameStack frames = frameStack(spill, reinterpret_cast<float *>(s_lane_lds + fr.stack_entries * kBlock + threadIdx.x), fr.lds_frames, kBlock);
+    FrameStack frames = frameStack(spill, reinterpret_cast<float *>(s_lane_lds + fr_arg.stack_entries * kBlock + threadIdx.x), fr_arg.lds_frames, kBlock);
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
     // Taking a tile is two dependent round trips to memory (the head counter, then the list entry), a
     // few microseconds during which the wave does nothing -- as long as a cheap tile takes to trace.  The

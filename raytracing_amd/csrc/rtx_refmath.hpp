@@ -74,6 +74,9 @@ RTX_DEV float refPowf(const RefMathTables &T, float x, float y) {
 // acosf, the division of the argument reduction in atanf -- is written once, on operands selected
 // per case.  Each case still performs exactly the operations fdlibm performs, in its order.
 
+// acosf / atan2f decide a texel of the environment map: unfused in the tolerance build as well (the pragma holds to the end of the file)
+#pragma clang fp contract(off)
+
 // fdlibm e_acosf
 RTX_DEV float refAcosf(float x) {
     const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
@@ -155,5 +158,9 @@ RTX_DEV float refAtan2f(float y, float x) {
         default: return (z - pi_lo) - pi;
     }
 }
+
+#ifdef RTX_FAST_MATH
+#pragma clang fp contract(fast)
+#endif
 
 }  // namespace rtx

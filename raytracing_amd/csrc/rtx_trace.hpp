@@ -397,6 +397,7 @@ RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastStat
 template <bool STATS, bool WIDE>
 RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, const CastState &cs,
                      Hit &h, float &min_dist, LaneCounters<STATS> &lc) {
+#pragma clang fp contract(off)  // hit points and texel coordinates: geometry, never contracted (see rtx_device.hpp)
     float minDist = cs.minDist;
     int kind = cs.kind, index = cs.index;
     // water plane, src/Scene.cpp:38-54
@@ -514,6 +515,7 @@ RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 
 // that translation unit; the two quotients are then formed in double and truncated to int; the
 // row shift wraps in uint32 before the modulo.  Texel = byte * (1/255.0f) (:429-434).
 RTX_DEV V3 skyColor(const DevScene &s, V3 dir) {
+#pragma clang fp contract(off)
     const int width = s.sky_w, height = s.sky_h;
     const float at = refAtan2f(dir.z, dir.x);
     const float ac = refAcosf(dir.y);
@@ -684,6 +686,7 @@ RTX_DEV LightAim aimLight(const DevScene &s, const SmallScene &q, const PathStat
 
 // the shadow ray towards an aimed light becomes the pending ray, :65-70
 RTX_DEV void pathAimShadowRay(const DevScene &s, PathState &st, const LightAim &a) {
+#pragma clang fp contract(off)
     st.ndl = a.ndl;
     st.orig = st.point + st.N * (__builtin_signbit(a.ndl) ? -s.fprec : s.fprec);  // (= point - N * fprec bit for bit on the far side)
     st.dir = a.dir;
@@ -797,9 +800,12 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         } else {
             // the child's origin: the point moved along N to the side the child leaves on.  point - N * e is
             // point + N * (-e) bit for bit, which saves choosing between two vectors
-            const auto childOrigin = [&](V3 d) { return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec); };
+            const auto childOrigin = [&](V3 d) {
+#pragma clang fp contract(off)
+                return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec);
+            };
             V3 reflD = v3(0, 0, 0), refrD = v3(0, 0, 0);
-            if (doRefl) reflD = normalize(reflect(dir, st.N));
+            if (doRefl) reflD = reflectDir(dir, st.N);
             if (doRefr) refrD = normalize(refractDir(dir, st.N, m.refractive));
             if (depth == 1) {
                 // the children have depth 0: traceRay returns the sky colour of their direction at

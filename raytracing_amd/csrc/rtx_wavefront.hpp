@@ -378,9 +378,12 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
             const V3 base = v3(m.dr * st.Ld * m.a0, m.dg * st.Ld * m.a0, m.db * st.Ld * m.a0) + v3(st.Ls * m.a1, st.Ls * m.a1, st.Ls * m.a1);
             doRefl = !s.prune || m.a2 != 0.0f;
             doRefr = !s.prune || m.a3 != 0.0f;
-            const auto childOrigin = [&](V3 d) { return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec); };
+            const auto childOrigin = [&](V3 d) {
+#pragma clang fp contract(off)
+                return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec);
+            };
             if (doRefl) {
-                reflD = normalize(reflect(dir, st.N));
+                reflD = reflectDir(dir, st.N);
                 reflO = childOrigin(reflD);
             }
             if (doRefr) {
