@@ -244,10 +244,11 @@ RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist, boo
 // the stored edges e1 = v1 - v0, e2 = v2 - v0.  v0 - v1 is -(v1 - v0) exactly, except that equal
 // coordinates give +0 both ways round; 0.0f - e reproduces that (0 - (+0) = +0, 0 - x = -x), so
 // the normal comes out with the reference's signed zeros too.
-RTX_DEV V3 triNormal(V3 edge1, V3 edge2) {
+// Returns the cross product; the caller normalizes (one normalize for whatever kind of surface a lane has hit).
+RTX_DEV V3 triNormalDir(V3 edge1, V3 edge2) {
     const V3 a = v3(0.0f - edge1.x, 0.0f - edge1.y, 0.0f - edge1.z);
     const V3 b = v3(0.0f - edge2.x, 0.0f - edge2.y, 0.0f - edge2.z);
-    return normalize(cross(a, b));
+    return cross(a, b);
 }
 
 // Cube::rayIntersect(orig, dir, nearDist, farDist), src/SceneObjects.cpp:101-139.  An origin
@@ -313,8 +314,8 @@ RTX_DEV int truncToIntD(double v) {
     return (int)v;
 }
 
-// Normal of Cube::rayIntersect(orig, dir, dist, n), src/SceneObjects.cpp:146-172
-RTX_DEV V3 boxNormal(const float lo[3], const float hi[3], V3 hit) {
+// Normal of Cube::rayIntersect(orig, dir, dist, n), src/SceneObjects.cpp:146-172, before its normalize (the caller's)
+RTX_DEV V3 boxNormalDir(const float lo[3], const float hi[3], V3 hit) {
     V3 c = (v3(lo[0], lo[1], lo[2]) + v3(hi[0], hi[1], hi[2])) * 0.5f;
     V3 d = (v3(lo[0], lo[1], lo[2]) - v3(hi[0], hi[1], hi[2])) * 0.5f;
     V3 p = hit - c;
@@ -333,7 +334,7 @@ RTX_DEV V3 boxNormal(const float lo[3], const float hi[3], V3 hit) {
         else
             iv3 = 1;
     }
-    return normalize(v3((float)iv1, (float)iv2, (float)iv3));
+    return v3((float)iv1, (float)iv2, (float)iv3);
 }
 
 // the direction of a mirrored ray, src/Scene.cpp:97

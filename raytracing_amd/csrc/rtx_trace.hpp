@@ -442,34 +442,37 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     // ---- resolve the winner: hit point, normal, material ----
     if (kind == 0) return false;
     h.point = orig + dir * minDist;
+    // The normal's direction per kind of surface, then ONE normalize for the lanes whose surface needs it: the lanes of a
+    // wave have hit different kinds, and a wave pays for every branch some lane takes -- the square root and the division
+    // of a normalize four times over otherwise.
     int mat = 0;
+    V3 n = v3(0.0f, 1.0f, 0.0f);  // the planes'
     if (kind == 1) {
         float4 sp;
         if (WIDE && s.sphere_bvh) sp = s.spheres[index], mat = s.sphere_mat[index];
         else sp = q.spheres[index], mat = q.sphere_mat[index];
-        h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
+        n = h.point - v3(sp.x, sp.y, sp.z);
     } else if (kind == 2) {
         const float *t = triAt<WIDE>(s, q, index);
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
-        h.N = triNormal(v1 - v0, v2 - v0);
+        n = triNormalDir(v1 - v0, v2 - v0);
         mat = triMatAt<WIDE>(s, q, index);
     } else if (kind == 3) {
         const float *b = boxAt<WIDE>(s, q, index);
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
-        h.N = boxNormal(lo, hi, h.point);
+        n = boxNormalDir(lo, hi, h.point);
         mat = boxMatAt<WIDE>(s, q, index);
     } else if (kind == 4) {
         const float4 *tp = s.mesh_tris + 3 * (size_t)index;
         const float4 p1 = tp[1], p2 = tp[2];
-        h.N = triNormal(v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z));
+        n = triNormalDir(v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z));
         mat = s.mesh_mat;
     } else if (kind == 5) {
-        h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.water_mat;
     } else {
-        h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.island_mat;
     }
+    h.N = kind <= 4 ? normalize(n) : n;
     h.m = materialAt<WIDE>(s, q, mat);
     h.mat_index = mat;
     if (kind == 5) {
@@ -652,6 +655,7 @@ RTX_DEV void pathCountRay(const PathState &st, int quad_j, LaneCounters<STATS> &
 // One light of calcLightning, src/Scene.cpp:64-79, in three pieces.
 struct LightAim {
     V3 pos, dir;  // the light, the unit vector towards it
+    float dist;   // distance(light, point), src/Scene.cpp:70
     float ndl, intensity;
     bool counts;  // false: the light can add to neither sum, its shadow ray decides nothing
 };
@@ -662,7 +666,11 @@ RTX_DEV LightAim aimLight(const DevScene &s, const SmallScene &q, const PathStat
     const float4 L = lightAt<WIDE>(s, q, li);
     a.pos = v3(L.x, L.y, L.z);
     a.intensity = L.w;
-    a.dir = normalize(a.pos - st.point);
+    // normalize(light - point) and distance(light, point) share their square root: the reference forms the second from
+    // point - light, whose components are the negated ones, and the squares of those are the same numbers
+    const V3 to_light = a.pos - st.point;
+    a.dist = sqrtf(dot(to_light, to_light));
+    a.dir = to_light * (1.0f / a.dist);
     a.ndl = dot(a.dir, st.N);
     a.counts = true;
     if (s.prune) {
@@ -690,7 +698,7 @@ RTX_DEV void pathAimShadowRay(const DevScene &s, PathState &st, const LightAim &
     st.ndl = a.ndl;
     st.orig = st.point + st.N * (__builtin_signbit(a.ndl) ? -s.fprec : s.fprec);  // (= point - N * fprec bit for bit on the far side)
     st.dir = a.dir;
-    st.lightDist = distance(a.pos, st.point);
+    st.lightDist = a.dist;
     // A hit nearer than this decides the reference's test for certain: the closest hit is then at
     // least that near, and |orig + dir*t - orig| differs from t by a few ulp only.
     st.t_exit = fminf(st.lightDist * 0.999f, s.far_clip);

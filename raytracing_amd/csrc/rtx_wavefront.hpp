@@ -328,7 +328,9 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_shadow(DevScene s,
         const float4 L = lightAt<WIDE>(s, q, (int)li);
         LightAim aim;
         aim.pos = v3(L.x, L.y, L.z), aim.intensity = L.w;
-        aim.dir = normalize(aim.pos - st.point);
+        const V3 to_light = aim.pos - st.point;
+        aim.dist = sqrtf(dot(to_light, to_light));
+        aim.dir = to_light * (1.0f / aim.dist);
         aim.ndl = dot(aim.dir, st.N);
         pathAimShadowRay(s, st, aim);
         RTX_COUNT(CNT_SHADOW);
