@@ -115,12 +115,10 @@ enum rtx_option {
                                  tiles in the order of what they cost in that frame; 0 = always the
                                  static order from projected bounding boxes.  Scheduling only: pixels
                                  do not change                                                       */
-    RTX_OPT_QUAD = 8,         /* 0/1/2/3 (default 1): with schedule feedback, tiles that lasted long in
+    RTX_OPT_QUAD = 8,         /* 0/1/2 (default 1): with schedule feedback, tiles that lasted long in
                                  the previous frame are traced with four lanes per pixel
                                  (the shadow rays of a node go out side by side): 0 never, 1 the tiles
-                                 that would hold the frame up (and the very longest of them one pixel
-                                 per wave), 2 every tile, 3 every tile with one pixel per wave (for
-                                 tests).  Pixels do not change                                       */
+                                 that would hold the frame up, 2 every tile.  Pixels do not change   */
     RTX_OPT_SPP = 9,          /* 1 (default) or 4: samples per pixel.  No counterpart in the reference
                                  (one ray through the pixel centre, src/Scene.cpp:217-218).  With 4,
                                  sample k goes through (col + 0.5 + dx[k], row + 0.5 + dy[k]) with

@@ -90,19 +90,12 @@ RTX_DEV void flushCounters(const LaneCounters<STATS> &lc, Counters *out) {
 // category tests, longer mesh walks) costs more than the idle lanes do.
 constexpr unsigned kQueues = 64, kHeadStride = 32;
 constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
-// One pixel of a tile as a list entry of its own (bit 30; bits 22-27 say which pixel, bits 0-21 which tile): the
-// wave that takes it gives the pixel four lanes, as in quad mode, and leaves the other sixty idle.  That is for the
-// very few tiles whose quarters would still outlast the rest of the frame -- the share of a frame that one GPU of
-// eight renders is over in the time a pixel behind three panes of glass needs for its sixty casts in a row.  A wave
-// with a single pixel runs through a trip in a third of the time (no other pixel's branches to sit through).
-constexpr unsigned kSoloFlag = 0x40000000u, kSoloTileMask = 0x003fffffu, kSoloPixelShift = 22;
 
 // Quad mode is for the tiles that lasted longer in the previous frame than a share (kQuadShare) of what
 // the whole frame would take if its work were spread evenly over all wave slots -- the ones that would
 // hold the frame up: they are entered as four quarters, all others once.  Never tiles shorter than
 // min_ticks, never more than `cap` tiles.
 constexpr float kQuadShare = 0.8f;
-constexpr float kSoloShare = 2.0f, kSoloBudget = 0.03f;  // (see kSoloFlag and launchRender)
 
 // The tile list of a frame from the costs of the previous one, without a sort: the tiles are dealt into
 // bins by cost on a logarithmic scale of eight steps per octave, most expensive first.  The bins above
@@ -116,9 +109,6 @@ RTX_DEV unsigned costBin(unsigned cost) {  // descending: bin 0 holds the most e
     const unsigned bits = __float_as_uint((float)cost) >> 20;  // exponent and three mantissa bits
     const unsigned b = bits > (127u << 3) ? bits - (127u << 3) : 0u;
     return kCostBins - 1u - (b < kCostBins ? b : kCostBins - 1u);
-}
-RTX_DEV float binFloor(unsigned bin) {  // the smallest cost that falls into `bin`
-    return __uint_as_float(((kCostBins - 1u - bin) + (127u << 3)) << 20);
 }
 // atomicAdd(&counters[bin], 1) for every lane with `valid`; returns the lane's own old value.  Most
 // tiles of a frame fall into a handful of bins (sky, water), and 64 atomics on one LDS address go one
@@ -171,11 +161,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const unsigned *__res
 // starts to write its tiles of bin b; head = {entries, first cheap entry, quad-mode tiles, quad-mode bins}
 // cheap_cost: tiles in the bins below this cost's bin count as cheap (k_render takes them in batches); 0 = below
 // the average cost
-// solo_share / solo_min_ticks / solo_cap / solo_budget: the same for the tiles entered pixel by pixel (kSoloFlag) -- those
-// at or above solo_share x the even share, never more than solo_cap tiles, nor more than hold solo_budget of all cost
 __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ block_hist, const unsigned long long *__restrict__ block_sum,
                                                         unsigned n, unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap,
-                                                        float solo_share, unsigned solo_min_ticks, unsigned solo_cap, float solo_budget,
                                                         unsigned cheap_cost, unsigned *__restrict__ n_out, unsigned *__restrict__ head) {
     __shared__ unsigned s_total[kCostBins], s_start[kCostBins];
     const unsigned b = threadIdx.x;
@@ -201,16 +188,6 @@ __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ b
             if (heavy + s_total[heavy_bins] > cap) break;
             heavy += s_total[heavy_bins];
         }
-        // pixel by pixel: the bins at the very top, as long as they stay within the cap and the budget
-        const float solo_even = solo_share * even;
-        const unsigned solo_limit_bin = costBin(solo_even > (float)solo_min_ticks ? (unsigned)fminf(solo_even, 4.0e9f) : solo_min_ticks);
-        unsigned solo = 0, solo_bins = 0;
-        float solo_cost = 0.0f;
-        for (; solo_bins < heavy_bins && solo_bins <= solo_limit_bin; ++solo_bins) {
-            const float bin_cost = (float)s_total[solo_bins] * binFloor(solo_bins);
-            if (solo + s_total[solo_bins] > solo_cap || solo_cost + bin_cost > solo_budget * (float)sum) break;
-            solo += s_total[solo_bins], solo_cost += bin_cost;
-        }
         unsigned pos = 0, cheap_from = n;
         const unsigned mean_bin = costBin(mean);
         for (unsigned k = 0; k < kCostBins; ++k) {
@@ -218,9 +195,9 @@ __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ b
             s_start[k] = pos, pos += s_total[k];
         }
         if (cheap_from < heavy) cheap_from = heavy;
-        n_out[0] = n + 3u * heavy + 60u * solo;  // a quad tile is four entries, a solo tile sixty-four
-        n_out[1] = 3u * heavy + 60u * solo + cheap_from;
-        head[0] = heavy, head[1] = heavy_bins, head[2] = solo, head[3] = solo_bins;
+        n_out[0] = n + 3u * heavy;
+        n_out[1] = 3u * heavy + cheap_from;
+        head[0] = heavy, head[1] = heavy_bins;
     }
     __syncthreads();
     for (unsigned g = 0; g < kBinBlocks; ++g) block_hist[g * kCostBins + b] += s_start[b];
@@ -232,19 +209,17 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_scatter(const unsigned *__r
     const unsigned t = threadIdx.x, first = blockIdx.x * per, last = first + per < n ? first + per : n;
     for (unsigned b = t; b < kCostBins; b += kBinThreads) s_cursor[b] = block_base[blockIdx.x * kCostBins + b];
     __syncthreads();
-    const unsigned heavy = head[0], heavy_bins = head[1], solo = head[2], solo_bins = head[3];
+    const unsigned heavy = head[0], heavy_bins = head[1];
     for (unsigned base = first; base < last; base += kBinThreads) {
         const unsigned i = base + t;
         const bool valid = i < last;
         const unsigned b = costBin(valid ? cost[i] : 0u);
         const unsigned pos = binSlot(s_cursor, b, valid);
         if (valid) {
-            if (b < solo_bins) {
-                for (unsigned px = 0; px < 64u; ++px) out[64u * pos + px] = i | (px << kSoloPixelShift) | kSoloFlag;
-            } else if (b < heavy_bins) {
-                for (unsigned sub = 0; sub < 4u; ++sub) out[60u * solo + 4u * pos + sub] = i | (sub << 28) | kQuadFlag;
+            if (b < heavy_bins) {
+                for (unsigned sub = 0; sub < 4u; ++sub) out[4u * pos + sub] = i | (sub << 28) | kQuadFlag;
             } else {
-                out[60u * solo + 3u * heavy + pos] = i;
+                out[3u * heavy + pos] = i;
             }
         }
     }
@@ -492,23 +467,20 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
         if (tile == 0xffffffffu) break;  // every queue is empty
         // An entry with kQuadFlag is a quarter (4x4 pixels, bits 28-29 say which) of a tile that lasted
         // long in the previous frame: four lanes share a pixel (quad mode of pathConsume).
-        // An entry with kSoloFlag is one pixel of a tile: four lanes trace it as in quad mode, the others idle.
-        const bool solo = (tile & kSoloFlag) != 0u;
-        const bool quad = solo || (tile & kQuadFlag) != 0u;
+        const bool quad = (tile & kQuadFlag) != 0u;
         const unsigned sub = (tile >> 28) & 3u;
-        const unsigned solo_px = (tile >> kSoloPixelShift) & 63u;
-        tile &= solo ? kSoloTileMask : kTileMask;
+        tile &= kTileMask;
         const int quad_j = quad ? (int)(lane & 3u) : -1;
         const unsigned pix = quad ? lane >> 2 : lane;  // pixel of the (sub-)tile this lane works on
-        const int side = solo ? 1 : (quad ? 4 : 8);
-        const unsigned side_shift = solo ? 0u : (quad ? 2u : 3u);
-        const int x0 = (int)(tile % tiles_x) * 8 + (solo ? (int)(solo_px & 7u) : (quad ? (int)(sub & 1u) * 4 : 0));
-        const int y0 = (int)(tile / tiles_x) * 8 + (solo ? (int)(solo_px >> 3) : (quad ? (int)(sub >> 1) * 4 : 0));
+        const int side = quad ? 4 : 8;
+        const unsigned side_shift = quad ? 2u : 3u;
+        const int x0 = (int)(tile % tiles_x) * 8 + (quad ? (int)(sub & 1u) * 4 : 0);
+        const int y0 = (int)(tile / tiles_x) * 8 + (quad ? (int)(sub >> 1) * 4 : 0);
         bool active;
         PixelJob job{0, 0};
         {
             const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
-            active = px < fr.width && pk < fr.rows && (!solo || pix == 0u);  // pixels of an edge tile outside the frame are skipped
+            active = px < fr.width && pk < fr.rows;  // pixels of an edge tile outside the frame are skipped
             if (active) {
                 const int row = fr.row_first + pk * fr.row_step;
                 job.row = row, job.col = px;
@@ -525,17 +497,13 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
         else tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
         // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)
-        // (a tile that went pixel by pixel is not measured: its last cost stands, less a sixteenth per frame, so that a
-        // tile which has become cheap -- the camera moves -- is measured again some frames later)
-        if (solo) {
-            if (lane == 0 && solo_px == 0u) tile_cost[tile] -= tile_cost[tile] >> 4;
-        } else if (lane == 0 && (!quad || sub == 0u)) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
+        if (lane == 0 && (!quad || sub == 0u)) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (dword_rows && !solo && x0 + side <= fr.width && y0 + side <= fr.rows) {
+        if (dword_rows && x0 + side <= fr.width && y0 + side <= fr.rows) {
             // rows of 24 (12) bytes: 48 (12) dword stores instead of 192 (48) byte stores
             const unsigned row_dwords = quad ? 3u : 6u;
             if (lane < row_dwords * (unsigned)side) {
@@ -543,7 +511,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
                 unsigned *dst = reinterpret_cast<unsigned *>(out + ((size_t)(y0 + (int)r) * fr.width + x0) * 3) + w;
                 *dst = *reinterpret_cast<const unsigned *>(&s_tile[threadIdx.x >> 6][4 * lane]);
             }
-        } else if (quad_j <= 0 && (!solo || pix == 0u)) {
+        } else if (quad_j <= 0) {
             const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
             if (px < fr.width && pk < fr.rows) {
                 const unsigned char *src = &s_tile[threadIdx.x >> 6][3 * pix];
@@ -663,10 +631,9 @@ struct SchedMem {
     unsigned *bins = nullptr;      // k_bin_*: per-workgroup histograms, then two words of header
     unsigned long long *bin_sums = nullptr;
     size_t cap = 0;                // tiles that cost and entries are sized for
-    size_t per_tile = 4;           // entries per tile that `entries` has room for
     bool quarters = true;          // entries has room for every tile as four quarters (quad mode)
 };
-constexpr size_t kHeadWords = 2 * kQueues * kHeadStride, kBinWords = kBinBlocks * kCostBins + 4;
+constexpr size_t kHeadWords = 2 * kQueues * kHeadStride, kBinWords = kBinBlocks * kCostBins + 2;
 
 // A view = camera + frame description, compared bit for bit.
 struct ViewKey {
@@ -913,17 +880,14 @@ bool tileRects(const rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, Tile
 // Grows the context's own scheduling memory to n tiles: cost per tile and the list built from it.
 int scheduleBuffers(rtx_ctx *c, size_t n) {
     SchedMem &m = c->sched;
-    if (n <= m.cap && (c->quad_mode != 3 || m.per_tile == 64)) return RTX_OK;
+    if (n <= m.cap) return RTX_OK;
     HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old buffers
     (void)hipFree(m.cost);
     (void)hipFree(m.entries);
     m.cost = nullptr, m.entries = nullptr, m.cap = 0;
     c->sched_state.have_cost = false, c->sched_state.by_cost_key.valid = false, c->sched_state.static_key.valid = false;
     HIP_OR_FAIL(hipMalloc((void **)&m.cost, n * sizeof(unsigned)));
-    // four entries per tile: every tile as four quarters, or (RTX_OPT_QUAD = 1) an eighth of them as quarters and a
-    // sixty-fourth pixel by pixel; sixty-four per tile for RTX_OPT_QUAD = 3
-    m.per_tile = c->quad_mode == 3 ? 64 : 4;
-    HIP_OR_FAIL(hipMalloc((void **)&m.entries, m.per_tile * n * sizeof(unsigned)));
+    HIP_OR_FAIL(hipMalloc((void **)&m.entries, 4 * n * sizeof(unsigned)));
     HIP_OR_FAIL(hipMemset(m.cost, 0, n * sizeof(unsigned)));
     m.cap = n;
     return RTX_OK;
@@ -1072,7 +1036,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     const int variant = (c->stats ? 1 : 0) + (wide ? 2 : 0);
     const int resident = c->resident_blocks[variant];
     fr.lds_frames = std::max(0, std::min(f->depth - 1, c->lds_frame_slots[variant]));  // a frame of depth d has at most d - 1 nodes waiting
-    const long long want = ((long long)m.per_tile * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
+    const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
     HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
@@ -1081,17 +1045,8 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     if (how == kFromCosts || how == kFromClasses) {
         const bool by_cost = how == kFromCosts;
         // RTX_OPT_QUAD: 0 never, 1 the tiles that would hold the frame up (never one shorter than 0.2 ms,
-        // never more than an eighth of all), 2 every tile; never on a list made from classes.  With 1, the tiles that
-        // cost more than kSoloShare x the even share -- whose quarters would still hold the frame up -- go pixel by
-        // pixel: never one shorter than 0.2 ms, never more than a sixty-fourth of all tiles, nor more than hold 3 % of
-        // all cost (a tile taken that way occupies ten times the wave slots).  That never happens to a whole 4K frame
-        // on one GPU; of the share of one GPU in four or eight it takes 10 - 15 % (what is left is the longest single
-        // pixel: some sixty casts one after the other, 0.2 ms).  3: every tile pixel by pixel.
-        const bool quads = by_cost && m.quarters && c->quad_mode != 0;
-        const unsigned cap = !quads ? 0u : (c->quad_mode >= 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
-        const bool solos = quads && (c->quad_mode == 1 || c->quad_mode == 3) && n_tiles <= (long long)kSoloTileMask;
-        const unsigned solo_cap = !solos ? 0u : (c->quad_mode == 3 ? (unsigned)n_tiles : (unsigned)(n_tiles / 64));
-        const bool all = c->quad_mode >= 2;
+        // never more than an eighth of all), 2 every tile; never on a list made from classes
+        const unsigned cap = !by_cost || !m.quarters || c->quad_mode == 0 ? 0u : (c->quad_mode == 2 ? (unsigned)n_tiles : (unsigned)(n_tiles / 8));
         const unsigned per = (unsigned)((n_tiles + kBinBlocks - 1) / kBinBlocks);
         unsigned *const d_head = m.bins + kBinBlocks * kCostBins;
         if (!by_cost)
@@ -1099,8 +1054,7 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
                                (unsigned)tiles_x, f->row_first, f->row_step, m.cost);
         hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, m.bin_sums);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, m.bins, m.bin_sums, (unsigned)n_tiles,
-                           (unsigned)resident * (kBlock / 64u), all ? 0.0f : kQuadShare, all ? 0u : 20000u, cap,
-                           all ? 0.0f : kSoloShare, all ? 0u : 20000u, solo_cap, all ? 2.0f : kSoloBudget,
+                           (unsigned)resident * (kBlock / 64u), c->quad_mode == 2 ? 0.0f : kQuadShare, c->quad_mode == 2 ? 0u : 20000u, cap,
                            by_cost ? 0u : kClassCheapCost, m.list_hdr, d_head);
         hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, d_head,
                            m.entries);
@@ -1352,7 +1306,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_SURFACE_BIAS: c->fprec = f; break;
         case RTX_OPT_SCHEDULE_FEEDBACK: c->feedback = value != 0; break;
         case RTX_OPT_QUAD:
-            if (value > 3) return fail(RTX_E_INVALID, "RTX_OPT_QUAD: 0 never, 1 automatic, 2 every tile, 3 every tile pixel by pixel");
+            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD: 0 never, 1 automatic, 2 every tile");
             c->quad_mode = (int)value;
             c->sched_state.by_cost_key.valid = false;  // the entry list is rebuilt with the next frame
             break;

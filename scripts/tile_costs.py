@@ -64,7 +64,6 @@ def run(workloads):
         top = np.argsort(c)[::-1][:3000]
         ys, xs = top // tx, top % tx
         print("   the 3000 dearest tiles lie in tile rows %d..%d, tile columns %d..%d" % (ys.min(), ys.max(), xs.min(), xs.max()))
-        print("   the 24 dearest tiles (tile row, tile column, us): " + " ".join("(%d,%d,%.0f)" % (t // tx, t % tx, c[t]) for t in top[:24]))
         # a coarse map: mean cost per 16 x 16 block of tiles
         by, bx = (ty + 15) // 16, (tx + 15) // 16
         print("   mean cost (us) per block of 16 x 16 tiles:")
