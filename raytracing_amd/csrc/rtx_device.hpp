@@ -244,7 +244,7 @@ RTX_DEV bool triHit(V3 v0, V3 edge1, V3 edge2, V3 orig, V3 dir, float &dist, boo
 // the stored edges e1 = v1 - v0, e2 = v2 - v0.  v0 - v1 is -(v1 - v0) exactly, except that equal
 // coordinates give +0 both ways round; 0.0f - e reproduces that (0 - (+0) = +0, 0 - x = -x), so
 // the normal comes out with the reference's signed zeros too.
-// Returns the cross product; the caller normalizes (one normalize for whatever kind of surface a lane has hit).
+// Returns the cross product; the caller normalizes.
 RTX_DEV V3 triNormalDir(V3 edge1, V3 edge2) {
     const V3 a = v3(0.0f - edge1.x, 0.0f - edge1.y, 0.0f - edge1.z);
     const V3 b = v3(0.0f - edge2.x, 0.0f - edge2.y, 0.0f - edge2.z);

@@ -442,37 +442,34 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     // ---- resolve the winner: hit point, normal, material ----
     if (kind == 0) return false;
     h.point = orig + dir * minDist;
-    // The normal's direction per kind of surface, then ONE normalize for the lanes whose surface needs it: the lanes of a
-    // wave have hit different kinds, and a wave pays for every branch some lane takes -- the square root and the division
-    // of a normalize four times over otherwise.
     int mat = 0;
-    V3 n = v3(0.0f, 1.0f, 0.0f);  // the planes'
     if (kind == 1) {
         float4 sp;
         if (WIDE && s.sphere_bvh) sp = s.spheres[index], mat = s.sphere_mat[index];
         else sp = q.spheres[index], mat = q.sphere_mat[index];
-        n = h.point - v3(sp.x, sp.y, sp.z);
+        h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
     } else if (kind == 2) {
         const float *t = triAt<WIDE>(s, q, index);
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
-        n = triNormalDir(v1 - v0, v2 - v0);
+        h.N = normalize(triNormalDir(v1 - v0, v2 - v0));
         mat = triMatAt<WIDE>(s, q, index);
     } else if (kind == 3) {
         const float *b = boxAt<WIDE>(s, q, index);
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
-        n = boxNormalDir(lo, hi, h.point);
+        h.N = normalize(boxNormalDir(lo, hi, h.point));
         mat = boxMatAt<WIDE>(s, q, index);
     } else if (kind == 4) {
         const float4 *tp = s.mesh_tris + 3 * (size_t)index;
         const float4 p1 = tp[1], p2 = tp[2];
-        n = triNormalDir(v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z));
+        h.N = normalize(triNormalDir(v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z)));
         mat = s.mesh_mat;
     } else if (kind == 5) {
+        h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.water_mat;
     } else {
+        h.N = v3(0.0f, 1.0f, 0.0f);
         mat = s.island_mat;
     }
-    h.N = kind <= 4 ? normalize(n) : n;
     h.m = materialAt<WIDE>(s, q, mat);
     h.mat_index = mat;
     if (kind == 5) {
