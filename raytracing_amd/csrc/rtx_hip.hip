@@ -370,9 +370,9 @@ extern __shared__ int s_lane_lds[];
 
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam_arg, DevFrame fr_arg, unsigned tiles_x_arg, unsigned n_tiles,
-                                                   const unsigned *__restrict__ order_arg, const unsigned *__restrict__ n_entries_dev,
+                                                   const unsigned *order_arg, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned batch_from_arg, unsigned *heads_arg, unsigned *heads_next,
-                                                   unsigned *__restrict__ tile_cost_arg, unsigned char *__restrict__ out_arg,
+                                                   unsigned *tile_cost_arg, unsigned char *out_arg,
                                                    Counters *counters) {
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
@@ -396,13 +396,14 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, De
     }
     loadSmallScene(q, s);
     __syncthreads();
-    const DevCamera &cam = ta.cam;
-    const DevFrame &fr = ta.fr;
-    const unsigned &tiles_x = ta.tiles_x;
-    const unsigned *const &order = ta.order;
-    unsigned *const &heads = ta.heads;
-    unsigned *const &tile_cost = ta.tile_cost;
-    unsigned char *const &out = ta.out;
+    // (not in the general build: it is short of vector registers rather than scalar ones, and spills more this way)
+    const DevCamera &cam = *(WIDE ? &cam_arg : &ta.cam);
+    const DevFrame &fr = *(WIDE ? &fr_arg : &ta.fr);
+    const unsigned &tiles_x = *(WIDE ? &tiles_x_arg : &ta.tiles_x);
+    const unsigned *const &order = *(WIDE ? &order_arg : &ta.order);
+    unsigned *const &heads = *(WIDE ? &heads_arg : &ta.heads);
+    unsigned *const &tile_cost = *(WIDE ? &tile_cost_arg : &ta.tile_cost);
+    unsigned char *const &out = *(WIDE ? &out_arg : &ta.out);
     int *stack = s_lane_lds + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     // the queue heads come in two sets: this launch counts in one and clears the other for the next
