@@ -369,7 +369,7 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
 extern __shared__ int s_lane_lds[];
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 3) void k_render(DevScene s, DevCamera cam_arg, DevFrame fr_arg, unsigned tiles_x_arg, unsigned n_tiles,
+__global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevScene s, DevCamera cam_arg, DevFrame fr_arg, unsigned tiles_x_arg, unsigned n_tiles,
                                                    const unsigned *order_arg, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned batch_from_arg, unsigned *heads_arg, unsigned *heads_next,
                                                    unsigned *tile_cost_arg, unsigned char *out_arg,
