@@ -246,11 +246,21 @@ __global__ __launch_bounds__(256) void k_tile_classes(TileRects rects, unsigned 
     const float c0 = (float)(bx * 8u), c1 = (float)(bx * 8u + 7u);
     const float r0 = (float)(row_first + (long long)by * 8 * row_step);
     const float r1 = (float)(row_first + ((long long)by * 8 + 7) * row_step);
-    int cls = 2;
+    // Inside a class, the tiles near the middle of their rectangle first (up to twice the class's stand-in cost, which
+    // keeps the classes apart): an object fills the middle of its bounding box, the corners are mostly empty, and the
+    // tiles that last longest -- the mesh mirrored in itself -- should be under way in the first round of the dispatch.
+    unsigned best = kClassCost2;
     for (int k = 0; k < rects.n; ++k)
-        if (c1 >= rects.r[k][0] - 1 && c0 <= rects.r[k][1] + 1 && r1 >= rects.r[k][2] - 1 && r0 <= rects.r[k][3] + 1 && rects.cls[k] < cls)
-            cls = rects.cls[k];
-    cost[i] = cls == 0 ? kClassCost0 : (cls == 1 ? kClassCost1 : kClassCost2);
+        if (c1 >= rects.r[k][0] - 1 && c0 <= rects.r[k][1] + 1 && r1 >= rects.r[k][2] - 1 && r0 <= rects.r[k][3] + 1) {
+            const float half_w = 0.5f * (rects.r[k][1] - rects.r[k][0]) + 4.0f, half_h = 0.5f * (rects.r[k][3] - rects.r[k][2]) + 4.0f * (float)row_step;
+            const float dx = fabsf(0.5f * (c0 + c1) - 0.5f * (rects.r[k][0] + rects.r[k][1])) / half_w;
+            const float dy = fabsf(0.5f * (r0 + r1) - 0.5f * (rects.r[k][2] + rects.r[k][3])) / half_h;
+            const float off = fminf(fmaxf(dx, dy), 1.0f);
+            const unsigned base = rects.cls[k] == 0 ? kClassCost0 : kClassCost1;
+            const unsigned cst = base + (unsigned)((float)(base - 1u) * (1.0f - off));
+            best = cst > best ? cst : best;
+        }
+    cost[i] = best;
 }
 
 // The pixel a lane works on; with several samples per pixel (WIDE build only) the lane traces them
