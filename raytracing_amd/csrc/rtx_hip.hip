@@ -375,6 +375,12 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
     bgr[0] = toByte(sum.z), bgr[1] = toByte(sum.y), bgr[2] = toByte(sum.x);
 }
 
+// Device memory behind a pointer that has been through LDS (k_render's per-tile values): the compiler no longer knows
+// the address space and would use flat instructions, whose stores a wave has to wait for at its next LDS fence.
+using GlobalU32 = __attribute__((address_space(1))) unsigned;
+using GlobalU8 = __attribute__((address_space(1))) unsigned char;
+template <typename G, typename T> __device__ __forceinline__ G *inDeviceMemory(T *p) { return (G *)p; }
+
 // k_render's per-lane LDS (sized by the launch): the traversal stack, then the frame heads; dword k of lane t at [k * kBlock + t]
 extern __shared__ int s_lane_lds[];
 
@@ -454,13 +460,14 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
             const unsigned len = __builtin_amdgcn_readlane(my_len, qi);
             const unsigned want = cheap_zone ? batch_max : 1u;
             unsigned i = len;
-            if (lane == 0 && len) i = atomicAdd(heads + qi * kHeadStride, want);
+            if (lane == 0 && len)
+                i = __hip_atomic_fetch_add(inDeviceMemory<GlobalU32>(heads + qi * kHeadStride), want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             i = __builtin_amdgcn_readfirstlane(i);
             if (i < len) {
                 const unsigned n = want < len - i ? want : len - i;
                 const unsigned e = qi + (i + lane) * kQueues;
                 batch = 0xffffffffu;
-                if (lane < n) batch = order ? order[e] : e;
+                if (lane < n) batch = order ? *inDeviceMemory<const GlobalU32>(order + e) : e;
                 batch_n = n, batch_k = 1u;
                 cheap_zone = qi + (i + n) * kQueues >= batch_from;
                 tile = __builtin_amdgcn_readlane(batch, 0);
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
             }
             // this queue is empty: every lane looks at one head, the wave moves to the next queue
             // (cyclically after qi) that still has entries, or leaves when there is none
-            const unsigned head = __hip_atomic_load(heads + lane * kHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned head = __hip_atomic_load(inDeviceMemory<GlobalU32>(heads + lane * kHeadStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long live = __ballot(head < my_len);
             live &= ~(1ull << qi);
             if (!live) break;
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
         else tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
         // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)
-        if (lane == 0 && (!quad || sub == 0u)) tile_cost[tile] = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
+        if (lane == 0 && (!quad || sub == 0u)) *inDeviceMemory<GlobalU32>(tile_cost + tile) = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -519,14 +526,14 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
             const unsigned row_dwords = quad ? 3u : 6u;
             if (lane < row_dwords * (unsigned)side) {
                 const unsigned r = lane / row_dwords, w = lane % row_dwords;
-                unsigned *dst = reinterpret_cast<unsigned *>(out + ((size_t)(y0 + (int)r) * fr.width + x0) * 3) + w;
+                GlobalU32 *dst = inDeviceMemory<GlobalU32>(reinterpret_cast<unsigned *>(out + ((size_t)(y0 + (int)r) * fr.width + x0) * 3) + w);
                 *dst = *reinterpret_cast<const unsigned *>(&s_tile[threadIdx.x >> 6][4 * lane]);
             }
         } else if (quad_j <= 0) {
             const int px = x0 + (int)(pix & (unsigned)(side - 1)), pk = y0 + (int)(pix >> side_shift);
             if (px < fr.width && pk < fr.rows) {
                 const unsigned char *src = &s_tile[threadIdx.x >> 6][3 * pix];
-                unsigned char *p = out + ((size_t)pk * fr.width + px) * 3;
+                GlobalU8 *p = inDeviceMemory<GlobalU8>(out + ((size_t)pk * fr.width + px) * 3);
                 p[0] = src[0], p[1] = src[1], p[2] = src[2];
             }
         }
