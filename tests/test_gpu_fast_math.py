@@ -33,6 +33,10 @@ def test_fast_math_frame_within_the_stated_tolerance(hip, fast, textures, mask, 
     print("mask %d %s %dx%d d%d: psnr %.2f dB, %.4f %% of pixels within 1/255, %d pixels differ at all, %d by more than 1: %s%s"
           % (mask, sky, W, H, depth, psnr, 100 * within, differ, len(bad), bad[:40], " ..." if len(bad) > 40 else ""))
     assert psnr >= PSNR_MIN_DB and within >= WITHIN_ONE_MIN
+    # The stated tolerance is the bar; the build is far inside it because its geometry is the exact build's (only shading
+    # arithmetic fuses): a handful of pixels off by one level.  A build that contracts the geometry too sits AT the bar
+    # (99.89 - 99.91 % on the spheres-and-planes frame, by the compiler's whim) -- catch that before it tips over.
+    assert len(bad) == 0 and differ <= W * H // 10000, (len(bad), differ)
 
 
 def test_fast_math_is_a_different_build(hip, fast):
