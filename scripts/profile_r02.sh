@@ -7,11 +7,11 @@ OUT=$ROOT/gpurun_out/prof_r02
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for W in ${@:-4k planes4k bunny4k 8k stress4k}; do
-  STEPS=100; [ "$W" = stress4k ] && STEPS=5
-  timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$W" -o "$W" --output-format csv -- python3 "$ROOT/bench.py" --workload $W --steps $STEPS --warmup 5 --no-cpu-baseline --no-counters --no-extras > "$OUT/profiled_$W.json" 2> "$OUT/profiled_$W.err" || { echo "trace of $W failed"; tail -5 "$OUT/profiled_$W.err"; exit 1; }
+  STEPS=100; WARM=5; LIMIT=400; [ "$W" = stress4k ] && STEPS=5; [ "$W" = stress ] && { STEPS=3; WARM=1; LIMIT=900; }
+  timeout -s KILL $LIMIT rocprofv3 --kernel-trace --stats -d "$OUT/trace_$W" -o "$W" --output-format csv -- python3 "$ROOT/bench.py" --workload $W --steps $STEPS --warmup $WARM --no-cpu-baseline --no-counters --no-extras > "$OUT/profiled_$W.json" 2> "$OUT/profiled_$W.err" || { echo "trace of $W failed"; tail -5 "$OUT/profiled_$W.err"; exit 1; }
   find "$OUT/trace_$W" -name "*kernel_stats.csv" -exec cp {} "$OUT/r02_${W}_kernel_stats.csv" \;
   rm -rf "$OUT/trace_$W"
-  timeout -k 10 400 python3 "$ROOT/bench.py" --workload $W --steps $STEPS --warmup 5 > "$OUT/r02_bench_$W.json" 2> "$OUT/bench_$W.err" || { echo "bench of $W failed"; tail -5 "$OUT/bench_$W.err"; exit 1; }
+  timeout -k 10 $LIMIT python3 "$ROOT/bench.py" --workload $W --steps $STEPS --warmup $WARM > "$OUT/r02_bench_$W.json" 2> "$OUT/bench_$W.err" || { echo "bench of $W failed"; tail -5 "$OUT/bench_$W.err"; exit 1; }
   echo "== $W"; cut -d, -f1-6 "$OUT/r02_${W}_kernel_stats.csv" | head -8
   python3 -c "
 import json,sys
