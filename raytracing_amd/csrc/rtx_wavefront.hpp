@@ -202,7 +202,7 @@ RTX_DEV bool wfSamplePixel(const DevFrame &fr, const WfStrip &strip, unsigned i,
 extern __shared__ int s_wf_stack[];
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_trace(DevScene s, DevCamera cam, DevFrame fr, WfStrip strip, WfArgs a,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_trace(DevScene s, DevCamera cam, DevFrame fr, WfStrip strip, WfArgs a,
                                                                     Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_trace(DevScene s, 
 }
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : 4) void k_wf_shadow(DevScene s, WfArgs a, Counters *counters) {
+__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(DevScene s, WfArgs a, Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
     loadSmallScene(q, s);

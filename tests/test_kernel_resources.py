@@ -10,14 +10,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
-#           kernel                        most scratch bytes per lane, most spilled VGPRs
-LIMITS = {"k_render<false, false>": (512, 16),      # the frames of the recursion beyond the LDS slots live there
-          "k_wf_trace<false, false>": (64, 12),
-          "k_wf_trace<false, true>": (64, 12),
-          "k_wf_shadow<false, false>": (0, 0),
-          "k_wf_shadow<false, true>": (0, 0),
-          "k_wf_shade<false, false>": (0, 0),
-          "k_wf_shade<false, true>": (0, 0)}
+#           kernel                        most scratch bytes per lane, most spilled VGPRs, most VGPRs
+LIMITS = {"k_render<false, false>": (512, 16, 168),  # three waves per SIMD; the frames of the recursion beyond the LDS slots live in scratch
+          "k_wf_trace<false, false>": (64, 12, 128),  # the pipeline's walking kernels: four waves per SIMD ...
+          "k_wf_shadow<false, false>": (0, 0, 128),
+          "k_wf_trace<false, true>": (192, 48, 96),   # ... and five in the general build (a stress-scene frame takes 4 % less
+          "k_wf_shadow<false, true>": (64, 16, 96),   # time with these spills and five waves than without them and four)
+          "k_wf_shade<false, false>": (0, 0, 128),
+          "k_wf_shade<false, true>": (0, 0, 128)}
 
 
 @pytest.fixture(scope="module")
@@ -35,8 +35,8 @@ def test_every_hot_kernel_is_in_the_library(resources):
 
 @pytest.mark.parametrize("kernel", sorted(LIMITS))
 def test_hot_kernels_keep_within_their_registers(resources, kernel):
-    scratch, spills = LIMITS[kernel]
+    scratch, spills, vgprs = LIMITS[kernel]
     r = resources[kernel]
     print(kernel, r)
     assert r["private_segment_fixed_size"] <= scratch and r["vgpr_spill_count"] <= spills, (kernel, r)
-    assert r["vgpr_count"] <= 168  # three waves per SIMD (four for the pipeline's kernels: 128)
+    assert r["vgpr_count"] <= vgprs
