@@ -79,7 +79,7 @@ typedef struct rtx_stats {
     uint64_t shadow_rays;     /* sceneIntersect calls from calcLightning                       */
     uint64_t sky_lookups;     /* Sky::getColorAt calls                                         */
     uint64_t mesh_box_hits;   /* rays that passed the mesh bounding box                        */
-    uint64_t bvh_node_tests;  /* inner-node (four-box) tests; oracle: non-empty grid cells     */
+    uint64_t bvh_node_tests;  /* inner-node (two-box) tests; oracle: non-empty grid cells      */
     uint64_t triangle_tests;  /* Moller-Trumbore tests on mesh triangles                       */
     uint64_t triangle_full;   /* ... of which got past the first (u) rejection                 */
     uint64_t sphere_tests;    /* Sphere::rayIntersect calls                                    */
@@ -135,11 +135,6 @@ enum rtx_option {
                                  ray counts; level by level has no schedule feedback and no quad mode */
     RTX_OPT_PIPELINE_BUDGET_MB = 11, /* MiB of device memory the arrays of RTX_OPT_PIPELINE = 1 may take (default
                                  16384); a frame that needs more is traced in strips of tiles      */
-    RTX_OPT_LDS_STACK = 12,   /* 1..16 (default 16), before rtx_commit: entries of a lane's traversal stack that the HIP
-                                 backend keeps in LDS; what a walk over the mesh's or the spheres' tree pushes beyond
-                                 them goes to scratch memory (rays rarely get that deep: the default holds all but a few
-                                 in a billion node visits of a 1.27 M-triangle mesh).  Results do not change; small
-                                 values exist for the tests of the overflow path                                   */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:
@@ -178,8 +173,8 @@ int rtx_set_triangles(rtx_ctx *ctx, const float *v9, const int *mat, int n);
 /* replaces: Model + BoundingBox + modelsIntersect (src/SceneObjects.cpp:176-255, 350-380).
  * verts = nv x {x,y,z} already scaled and offset; idx = nt x 3, zero-based.  The bounding box
  * that gates the mesh is the min/max over ALL nv vertices -/+ 1e-4 (src/SceneObjects.cpp:241-243).
- * The HIP backend builds a bounding volume hierarchy over the triangles on the GPU in rtx_commit()
- * (four children per node); the oracle builds the reference's 7x7x7 vertex-binned grid. */
+ * The HIP backend builds an LBVH over the triangles on the GPU in rtx_commit(); the oracle builds
+ * the reference's 7x7x7 vertex-binned grid. */
 int rtx_set_mesh(rtx_ctx *ctx, const float *verts, int nv, const int *idx, int nt, int mat);
 /* replaces: Scene::loadIslands + Island + islandsIntersect (src/Scene.cpp:159-166,
  * src/SceneObjects.cpp:273-287, 399-419; include/SceneObjects.h:101-113).

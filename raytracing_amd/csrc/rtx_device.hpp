@@ -59,25 +59,14 @@ struct Material {  // 9 floats, include/Material.h:8-18
     float refractive, a0, a1, a2, a3, dr, dg, db, spec;
 };
 
-// Binary tree node, 64 bytes, as the builders emit it: both children's boxes live in the parent.
-// child >= 0: inner node index; child < 0: ~child is a triangle index.  The walks read the four-wide nodes that
-// rtx_commit collapses these into (Bvh4Node).
+// BVH2 node, 64 bytes: both children's boxes live in the parent so one fetch decides two subtrees.
+// child >= 0: inner node index; child < 0: ~child is a triangle index.
 struct BvhNode {
     float lminx, lminy, lminz, lmaxx;
     float lmaxy, lmaxz, rminx, rminy;
     float rminz, rmaxx, rmaxy, rmaxz;
     int left, right, pad0, pad1;
 };
-
-// Four-wide node, 128 bytes: the boxes of the four children plane by plane (x of all four children in one
-// float4 ...), then the child ids (>= 0 inner node, < 0 leaf ~id; an unused slot has an empty box) and, in pad.x,
-// the number of children.  See bvh4_build.hpp.
-struct Bvh4Node {
-    float4 lox, loy, loz, hix, hiy, hiz;
-    int4 child;
-    int4 pad;
-};
-static_assert(sizeof(Bvh4Node) == 128, "the walks index the nodes by shifts");
 
 struct DevScene {
     // materials, lights
@@ -89,10 +78,10 @@ struct DevScene {
     const float4 *spheres;
     const int *sphere_mat;
     int n_spheres;
-    // More spheres than the LDS staging holds (kMaxSmallPrims): a four-wide tree over their boxes (leaf ~child =
+    // More spheres than the LDS staging holds (kMaxSmallPrims): a BVH2 over their boxes (leaf ~child =
     // sphere index), null otherwise.  The boxes are the geometric ones; the slack that the rounding
     // of Sphere::rayIntersect needs is added per ray (sphereWalk in rtx_trace.hpp).
-    const Bvh4Node *sphere_bvh;
+    const BvhNode *sphere_bvh;
     float sphere_root_c[3];  // centre of the box around all spheres
     float sphere_root_h;     // its half diagonal
     float sphere_rmax;       // largest radius
@@ -104,9 +93,9 @@ struct DevScene {
     const float *boxes;
     const int *box_mat;
     int n_boxes;
-    // mesh: triangles as v0, e1 = v1 - v0, e2 = v2 - v0 in three float4 (w unused), a four-wide tree over them
+    // mesh: triangles as v0, e1 = v1 - v0, e2 = v2 - v0 in three float4 (w unused), BVH2 over them
     const float4 *mesh_tris;
-    const Bvh4Node *bvh;
+    const BvhNode *bvh;
     int n_mesh_tris;
     int mesh_mat;
     float mesh_lo[3], mesh_hi[3];  // the gate box: all vertices -/+ 1e-4
@@ -142,7 +131,6 @@ struct DevScene {
     float fprec;     // 1e-3, include/Scene.h:23
     int prune;       // skip rays whose contribution is exactly nothing (zero-weight children, lights that cannot add)
     int lights_plain;  // every light intensity is finite and >= 0
-    int stack_cap;     // entries of a lane's traversal stack that live in LDS (the launch sizes the LDS for them)
 };
 
 // The analytic part of the scene (a few hundred bytes to a few KB) staged in LDS once per block.

@@ -18,7 +18,6 @@
 #include "../../include/rtx.h"
 #include "lbvh_build.hpp"
 #include "sah_build.hpp"
-#include "bvh4_build.hpp"
 #include "rtx_device.hpp"
 #include "rtx_trace.hpp"
 
@@ -27,9 +26,7 @@ using namespace rtx;
 namespace {
 
 constexpr int kBlock = 256;     // 4 waves per block
-constexpr int kStackDepth = kWalkStack;  // most traversal stack entries a walk may need (checked against what the scene's trees need)
-constexpr int kLdsStack = 16;   // ... of which at most this many per lane live in LDS, the rest in scratch memory (LaneStack)
-constexpr int kTreeDepth = 32;  // the builders bound their binary trees to this many levels
+constexpr int kStackDepth = 32; // LDS traversal stack entries per lane (checked against the tree's depth)
 constexpr int kMaxSpheres = 1 << 24;
 
 struct DevCamera {
@@ -276,7 +273,7 @@ struct PixelJob {
 // (include/bitmap_image.hpp:207-209) go to `bgr` (the wave's tile buffer in LDS).
 template <bool STATS, bool WIDE>
 __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, PixelJob job,
-                                           PathState &st, FrameStack &frames, bool active, const int quad_j, unsigned char *bgr, const LaneStack &stack,
+                                           PathState &st, FrameStack &frames, bool active, const int quad_j, unsigned char *bgr, int *stack,
                                            LaneCounters<STATS> &lc) {
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     int sample = 0;
@@ -286,7 +283,7 @@ __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &
         float md = 0.0f;
         if (pathCasts(st, quad_j)) {
             pathCountRay<STATS>(st, quad_j, lc);
-            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, lc);
+            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
         }
         V3 c;
         if (pathConsume<STATS, WIDE>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
@@ -321,7 +318,7 @@ RTX_DEV float sampleDy(int k) { return k == 0 ? 0.375f : (k == 1 ? 0.125f : (k =
 // sample order afterwards.
 template <bool STATS>
 __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, int x0, int y0,
-                                              PathState &st, FrameStack &frames, float *samples, unsigned char *tile_bgr, const LaneStack &stack,
+                                              PathState &st, FrameStack &frames, float *samples, unsigned char *tile_bgr, int *stack,
                                               LaneCounters<STATS> &lc) {
     const unsigned lane = threadIdx.x & 63u;
     const V3 eye = v3(cam.ox, cam.oy, cam.oz);
@@ -355,7 +352,7 @@ __device__ __forceinline__ void tracePathPool(const DevScene &s, const SmallScen
             float md = 0.0f;
             if (pathCasts(st, -1)) {
                 pathCountRay<STATS>(st, -1, lc);
-                hit = sceneIntersect<STATS, true>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, lc);
+                hit = sceneIntersect<STATS, true>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
             }
             V3 c;
             if (pathConsume<STATS, true>(s, q, st, frames, hit, h, md, -1, c, lc)) {
@@ -423,8 +420,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
     unsigned *const &heads = *(WIDE ? &heads_arg : &ta.heads);
     unsigned *const &tile_cost = *(WIDE ? &tile_cost_arg : &ta.tile_cost);
     unsigned char *const &out = *(WIDE ? &out_arg : &ta.out);
-    int stack_over[kWalkStack];
-    const LaneStack stack{s_lane_lds + threadIdx.x, kBlock, s.stack_cap, stack_over};
+    int *stack = s_lane_lds + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
     // the queue heads come in two sets: this launch counts in one and clears the other for the next
     // launch of the context (launches of a context follow one another), which saves a fill per frame
@@ -553,17 +549,15 @@ template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene s, const float *__restrict__ orig,
                                                        const float *__restrict__ dir, int n, int depth,
                                                        float *__restrict__ rgb) {
-    __shared__ int s_stack[kLdsStack * kBlock];
+    __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     loadSmallScene(q, s);
     __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     LaneCounters<false> lc;
-    int stack_over[kWalkStack];
-    const LaneStack stack{s_stack + threadIdx.x, kBlock, s.stack_cap, stack_over};
     const V3 c = traceRay<false, WIDE>(s, q, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
-                                 v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, stack, lc);
+                                 v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, s_stack + threadIdx.x, kBlock, lc);
     rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
 }
 
@@ -571,21 +565,20 @@ template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_intersect_rays(DevScene s, const float *__restrict__ orig,
                                                            const float *__restrict__ dir, int n,
                                                            float *__restrict__ out16) {
-    __shared__ int s_stack[kLdsStack * kBlock];
+    __shared__ int s_stack[kStackDepth * kBlock];
     __shared__ SmallScene q;
     loadSmallScene(q, s);
     __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     LaneCounters<false> lc;
-    int stack_over[kWalkStack];
-    const LaneStack stack{s_stack + threadIdx.x, kBlock, s.stack_cap, stack_over};
     Hit h;
     h.point = v3(0, 0, 0), h.N = v3(0, 0, 0);
     h.m = Material{1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // Material(), include/Material.h:14
     float md;
     const V3 from = v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]);
-    const bool ok = sceneIntersect<false, WIDE>(s, q, from, v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md, stack, lc);
+    const bool ok = sceneIntersect<false, WIDE>(s, q, from, v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), false, -1.0f, h, md,
+                                          s_stack + threadIdx.x, kBlock, lc);
     float *o = out16 + 16 * (size_t)i;
     o[0] = ok ? 1.0f : 0.0f;
     o[1] = h.point.x, o[2] = h.point.y, o[3] = h.point.z;
@@ -770,7 +763,7 @@ struct rtx_ctx {
     bool committed = false;
     DevScene dev{};
     std::vector<void *> owned;
-    int bvh_depth = 0;  // traversal stack entries the mesh tree's walk can have in use at once
+    int bvh_depth = 0;
     Counters *d_counters = nullptr;
     int resident_blocks[4] = {0, 0, 0, 0};  // grid size of k_render<STATS, WIDE>, index STATS + 2 * WIDE
     int spp = 1;                            // RTX_OPT_SPP
@@ -785,9 +778,8 @@ struct rtx_ctx {
     WfMem wf;
     int wf_stack_entries = kStackDepth;     // LDS traversal stack entries per lane of the pipeline's kernels
     int stack_entries = kStackDepth;        // ... and of k_render
-    int lds_stack = kLdsStack;              // RTX_OPT_LDS_STACK
     int lds_frame_slots[4] = {0, 0, 0, 0};  // frame heads of a lane that k_render keeps in LDS, per variant
-    int sphere_bvh_depth = 0;  // ... the sphere tree's
+    int sphere_bvh_depth = 0;
     int wf_blocks[3][4] = {};               // resident blocks of k_wf_trace / k_wf_shadow [STATS + 2 * WIDE], k_wf_shade [STATS]
     size_t wf_budget = (size_t)16 << 30;    // bytes the pipeline's arrays may take
     unsigned char *d_frame = nullptr;
@@ -798,25 +790,6 @@ namespace {
 
 int bind(rtx_ctx *c) {
     HIP_OR_FAIL(hipSetDevice(c->device));
-    return RTX_OK;
-}
-
-// The four-wide tree of a binary one: `host_nodes` (uploaded first) or the device array d_nodes of n_nodes.
-int wideTree(rtx_ctx *c, const std::vector<BvhNode> &host_nodes, const BvhNode *d_nodes, Bvh4Result *out, int n_nodes = 0) {
-    BvhNode *staged = nullptr;
-    if (!d_nodes) {
-        n_nodes = (int)host_nodes.size();
-        HIP_OR_FAIL(hipMalloc((void **)&staged, host_nodes.size() * sizeof(BvhNode)));
-        const hipError_t e = hipMemcpy(staged, host_nodes.data(), host_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(staged);
-            return failHip(e, "tree upload");
-        }
-        d_nodes = staged;
-    }
-    const hipError_t e = bvh4Collapse(d_nodes, n_nodes, c->stream, out);
-    (void)hipFree(staged);
-    if (e != hipSuccess) return failHip(e, "four-wide tree");
     return RTX_OK;
 }
 
@@ -1008,7 +981,6 @@ float farthestOrigin(const rtx_ctx *c, const float *orig, int n) {
 DevScene sceneForLaunch(const rtx_ctx *c, float origin_reach) {
     DevScene s = c->dev;
     s.prune = c->prune, s.far_clip = c->far_clip, s.fprec = c->fprec;
-    s.stack_cap = c->stack_entries;  // (the same for both pipelines and the probes: the LDS every launch asks for)
     sphereGateBounds(c, s, origin_reach);
     return s;
 }
@@ -1025,9 +997,8 @@ constexpr size_t renderLds(int stack_entries, int frame_slots) { return (size_t)
 int residentBlocks(rtx_ctx *c) {
     hipDeviceProp_t prop;
     HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
-    // traversal stacks as deep as the scene's trees need (one entry more: the walk stores before it counts), in LDS up
-    // to kLdsStack entries
-    c->stack_entries = std::max(1, std::min(c->lds_stack, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
+    // traversal stacks as deep as the scene's trees need (one entry more: the walk stores before it counts)
+    c->stack_entries = std::max(1, std::min(kStackDepth, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
     for (int variant = 0; variant < 4; ++variant) {
         int per_cu = 0;
         HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kRenderKernels[variant], kBlock, renderLds(c->stack_entries, 0)));
@@ -1132,7 +1103,7 @@ int wavefrontBlocks(rtx_ctx *c) {
     HIP_OR_FAIL(hipGetDeviceProperties(&prop, c->device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     // traversal stacks as deep as the scene's trees need (one entry more: the walk stores before it counts)
-    c->wf_stack_entries = std::max(1, std::min(c->lds_stack, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
+    c->wf_stack_entries = std::max(1, std::min(kStackDepth, std::max(c->bvh_depth, c->sphere_bvh_depth) + 1));
     const size_t lds = (size_t)c->wf_stack_entries * kBlock * sizeof(int);
     for (int v = 0; v < 4; ++v) {
         int per_cu = 0;
@@ -1375,11 +1346,6 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (value > 3) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 surface-area heuristic on the GPU, 1 Morton order on the GPU, 2 surface-area heuristic on the host, 3 clustering on the GPU");
             c->bvh_builder = (int)value;
             break;
-        case RTX_OPT_LDS_STACK:
-            if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_LDS_STACK must be set before rtx_commit");
-            if (value < 1 || value > (uint32_t)kLdsStack) return fail(RTX_E_INVALID, "RTX_OPT_LDS_STACK: 1 to 16 entries");
-            c->lds_stack = (int)value;
-            break;
         case RTX_OPT_MESH_GRID:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_MESH_GRID must be set before rtx_commit");
             c->mesh_grid = value != 0;
@@ -1595,16 +1561,12 @@ int rtx_commit(rtx_ctx *c) {
         }
         std::vector<BvhNode> nodes;
         SahBuilder builder(boxes);
-        builder.build(nodes, kTreeDepth);
-        Bvh4Result wide;
-        if (int e = wideTree(c, nodes, nullptr, &wide)) return e;
-        if (wide.stack_need + 1 > kStackDepth) {
-            (void)hipFree(wide.nodes);
-            return fail(RTX_E_LIMIT, "the sphere tree needs a deeper traversal stack than there is");
-        }
-        c->owned.push_back(wide.nodes);
-        c->sphere_bvh_depth = wide.stack_need;
-        d.sphere_bvh = wide.nodes;
+        const int depth = builder.build(nodes, kStackDepth);
+        if (depth > kStackDepth) return fail(RTX_E_LIMIT, "sphere BVH deeper than the traversal stack");
+        c->sphere_bvh_depth = depth;
+        BvhNode *dn;
+        if (int e = upload(nodes, &dn, c->owned)) return e;
+        d.sphere_bvh = dn;
         float h2 = 0.0f;
         for (int k = 0; k < 3; ++k) {
             d.sphere_root_c[k] = 0.5f * (all.lo[k] + all.hi[k]);
@@ -1644,35 +1606,22 @@ int rtx_commit(rtx_ctx *c) {
         LbvhResult r;
         const GpuTree gpu_tree = c->bvh_builder == 2 ? GpuTree::kNone
                                                       : (c->bvh_builder == 1 ? GpuTree::kMorton : (c->bvh_builder == 3 ? GpuTree::kCluster : GpuTree::kSah));
-        hipError_t he = lbvhBuild(dv, di, nt, gpu_tree, kTreeDepth, c->stream, &r);
+        hipError_t he = lbvhBuild(dv, di, nt, gpu_tree, kStackDepth, c->stream, &r);
         if (he != hipSuccess) return failHip(he, "mesh tree build");
-        c->owned.push_back(r.tris);
-        // the binary tree becomes a four-wide one (bvh4_build.hpp); only that one stays
-        Bvh4Result wide;
-        int rc = RTX_OK;
-        if (gpu_tree != GpuTree::kNone) rc = wideTree(c, std::vector<BvhNode>(), r.nodes, &wide, r.n_nodes);
-        if (rc == RTX_OK && (gpu_tree == GpuTree::kNone || wide.stack_need + 1 > kStackDepth)) {
-            (void)hipFree(wide.nodes);
-            wide = Bvh4Result();
+        c->owned.push_back(r.tris), c->owned.push_back(r.nodes);
+        if (gpu_tree == GpuTree::kNone || r.max_depth > kStackDepth) {
             std::vector<BvhNode> nodes;
             SahBuilder builder(c->mesh_verts, c->mesh_idx, kBvhPad);
-            // (a tree that came out too deep for the stack: the host builder, held to fewer levels)
-            int levels = 2;
-            while ((1ll << levels) < (long long)nt) ++levels;
-            builder.build(nodes, gpu_tree == GpuTree::kNone ? kTreeDepth : std::max(22, levels + 2));
-            rc = wideTree(c, nodes, nullptr, &wide);
+            r.max_depth = builder.build(nodes, kStackDepth);
+            HIP_OR_FAIL(hipMemcpy(r.nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
         }
-        (void)hipFree(r.nodes);
-        if (rc != RTX_OK) return rc;
-        if (wide.stack_need + 1 > kStackDepth) {
-            (void)hipFree(wide.nodes);
+        if (r.max_depth > kStackDepth) {
             char msg[160];
-            snprintf(msg, sizeof msg, "the mesh tree's walk needs %d stack entries, the traversal stack has %d", wide.stack_need + 1, kStackDepth);
+            snprintf(msg, sizeof msg, "LBVH depth %d exceeds the traversal stack (%d entries)", r.max_depth, kStackDepth);
             return fail(RTX_E_LIMIT, msg);
         }
-        c->owned.push_back(wide.nodes);
-        c->bvh_depth = wide.stack_need;
-        d.mesh_tris = r.tris, d.bvh = wide.nodes, d.n_mesh_tris = nt, d.mesh_mat = c->mesh_mat;
+        c->bvh_depth = r.max_depth;
+        d.mesh_tris = r.tris, d.bvh = r.nodes, d.n_mesh_tris = nt, d.mesh_mat = c->mesh_mat;
         d.mesh_cells = nullptr;
         if (c->mesh_grid) {
             std::vector<int> keys;
@@ -1720,12 +1669,6 @@ int rtx_commit(rtx_ctx *c) {
     }
     if (int e = residentBlocks(c)) return e;
     if (int e = wavefrontBlocks(c)) return e;
-    if (getenv("RTX_VERBOSE"))  // what the commit built, for the measurement scripts
-        fprintf(stderr, "rtx_commit: mesh tree walk needs %d stack entries, sphere tree %d; LDS stack entries %d (k_render) %d (level by level); "
-                        "resident workgroups k_render %d %d %d %d, k_wf_trace %d %d %d %d, k_wf_shadow %d %d %d %d\n",
-                c->bvh_depth, c->sphere_bvh_depth, c->stack_entries, c->wf_stack_entries, c->resident_blocks[0], c->resident_blocks[1],
-                c->resident_blocks[2], c->resident_blocks[3], c->wf_blocks[0][0], c->wf_blocks[0][1], c->wf_blocks[0][2], c->wf_blocks[0][3],
-                c->wf_blocks[1][0], c->wf_blocks[1][1], c->wf_blocks[1][2], c->wf_blocks[1][3]);
     c->committed = true;
     // host copies are no longer needed
     std::vector<unsigned char>().swap(c->sky);
@@ -1813,16 +1756,6 @@ int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {
     float ms = 0;
     HIP_OR_FAIL(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     o->kernel_ms = ms;
-#ifdef RTX_PROBE_SP
-    {
-        unsigned h[64];
-        HIP_OR_FAIL(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_hist), sizeof h));
-        fprintf(stderr, "stack entries in use after a node trip (cumulative over the process):");
-        for (int k = 0; k < 64; ++k)
-            if (h[k]) fprintf(stderr, " %d:%u", k, h[k]);
-        fprintf(stderr, "\n");
-    }
-#endif
     if (c->stats) {
         Counters h;
         HIP_OR_FAIL(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));

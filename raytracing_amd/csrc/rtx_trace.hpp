@@ -28,9 +28,10 @@ RTX_DEV bool firstActiveLane() {
     if constexpr (STATS) lc.v[slot] += (n)
 
 // ---------------------------------------------------------------------------------------------
-// Mesh: the walk over its tree.  Returns the closest front-facing hit under Triangle::rayIntersect with
+// Mesh: LBVH traversal.  Returns the closest front-facing hit under Triangle::rayIntersect with
 // t < best_t (strict, as modelsIntersect's `curDist < modelsDist && curDist < minDist`,
-// src/SceneObjects.cpp:365-366).  `stack` is the lane's traversal stack (LaneStack).
+// src/SceneObjects.cpp:365-366).  `stack` points at this lane's column of an LDS array whose rows
+// are `stride` ints apart, so the 64 lanes of a wave hit 64 different banks.
 // The walk stops at the first hit nearer than t_exit (shadow rays; closest-hit rays pass a
 // negative t_exit) and then returns true.
 // ---------------------------------------------------------------------------------------------
@@ -68,152 +69,59 @@ RTX_DEV int cellKey(const DevScene &s, int4 keys, V3 orig, V3 dir, V3 inv) {
     return key;
 }
 
-// ---------------------------------------------------------------------------------------------
-// One trip of a walk over a four-wide tree (bvh4_build.hpp): the lane tests the four child boxes of node `cur`
-// and goes on with the nearest one it passes; the others go onto its stack, farthest first.
-//
-// Box tests only steer a walk; they use reciprocals and FMA freely.  The boxes were padded when the tree was
-// built, and t_far is widened by 2 ulp, so a primitive the exact test would accept is never culled by rounding
-// here.  A lane reads the planes its ray meets first and last on every axis directly -- the node stores the four
-// children's planes side by side, lo before hi, and the lane's offsets (WideRay) pick lo or hi by the sign of its
-// direction -- so a box costs six multiply-adds, two three-way maxima / minima and a comparison.
-// plane distance = plane * inv + add, with separate addends for near and far planes (the sphere walk widens the
-// boxes per ray; the mesh walk passes the same three values twice).
-// ---------------------------------------------------------------------------------------------
-constexpr int kWalkDone = (int)0x80000000;  // nothing left on the stack
-
-// A lane's traversal stack.  How deep a walk can get in the worst case is known exactly per tree (bvh4_build.hpp)
-// and is several times what rays really reach (a 1.27 M-triangle tree: 39 entries possible, 19 seen, 99.99 % of
-// all node trips end with fewer than ten).  So only the first `cap` entries live in LDS -- entry k of the lane at
-// lds[k * stride], consecutive lanes in consecutive banks -- and whatever a walk pushes beyond them goes to the
-// lane's scratch memory: LDS is what bounds the workgroups per CU of the level-by-level kernels.
-constexpr int kWalkStack = 48;  // most entries a walk may need; rtx_commit holds the trees to it
-struct LaneStack {
-    int *lds;
-    int stride, cap;
-    int *over;  // kWalkStack entries, entry k at over[k - cap]
-};
-RTX_DEV void stackStore(const LaneStack &st, int k, int v) {
-    if (k < st.cap) st.lds[k * st.stride] = v;
-    else st.over[k - st.cap] = v;
-}
-// the top entry, or kWalkDone from an empty stack
-RTX_DEV int stackPop(const LaneStack &st, int &sp) {
-    int v = (int)0x80000000;
-    if (sp > 0) {
-        --sp;
-        if (__builtin_expect(sp < st.cap, 1)) v = st.lds[sp * st.stride];
-        else v = st.over[sp - st.cap];
-    }
-    return v;
-}
-#ifdef RTX_PROBE_SP
-__device__ unsigned g_sp_hist[64];  // measurement build: how many node trips ended with this many entries on the stack
-#endif
-struct WideRay {
-    float ix, iy, iz;                 // clamped reciprocals of the direction: no inf - inf in the plane distances
-    unsigned nx, ny, nz, fx, fy, fz;  // byte offsets, within a node, of the planes the ray meets first / last per axis
-};
-RTX_DEV WideRay wideRay(V3 inv) {
-    WideRay r;
-    r.ix = inv.x, r.iy = inv.y, r.iz = inv.z;
-    const unsigned sx = inv.x < 0.0f ? 48u : 0u, sy = inv.y < 0.0f ? 48u : 0u, sz = inv.z < 0.0f ? 48u : 0u;
-    r.nx = sx, r.fx = 48u - sx;
-    r.ny = 16u + sy, r.fy = 64u - sy;
-    r.nz = 32u + sz, r.fz = 80u - sz;
-    return r;
-}
-// Two floats side by side: the plane distances of two children come out of one packed multiply-add.
-typedef float WidePair __attribute__((ext_vector_type(2)));
-RTX_DEV WidePair widePlanes(float p0, float p1, float inv, float add) {
-    return __builtin_elementwise_fma(WidePair{p0, p1}, WidePair{inv, inv}, WidePair{add, add});
-}
-// Returns the node or leaf to go on with (kWalkDone when the stack has run dry).  ORDERED: the children the ray
-// passes are visited nearest first (closest-hit rays cull what lies behind a hit); a walk that only asks whether
-// anything is hit at all (shadow rays alone in a launch) takes them as they are stored and saves the sorting.
-// The three stores are unconditional: the slot at `sp` is free, and what is not counted is overwritten by the
-// next push.
-template <bool ORDERED>
-RTX_DEV int wideNodeTrip(const Bvh4Node *nodes, int cur, const WideRay &r, float anx, float any, float anz, float afx, float afy, float afz,
-                         float bound, const LaneStack &stack, int &sp) {
-    const char *base = reinterpret_cast<const char *>(nodes);
-    const unsigned at = (unsigned)cur << 7;
-    const float4 NX = *reinterpret_cast<const float4 *>(base + (at + r.nx)), NY = *reinterpret_cast<const float4 *>(base + (at + r.ny)),
-                 NZ = *reinterpret_cast<const float4 *>(base + (at + r.nz));
-    const float4 FX = *reinterpret_cast<const float4 *>(base + (at + r.fx)), FY = *reinterpret_cast<const float4 *>(base + (at + r.fy)),
-                 FZ = *reinterpret_cast<const float4 *>(base + (at + r.fz));
-    const int4 ch = *reinterpret_cast<const int4 *>(base + (at + 96u));
-    // distances to the planes the ray meets first (n) and last (f) on each axis, children 0 1 and 2 3 side by side
-    const WidePair nx01 = widePlanes(NX.x, NX.y, r.ix, anx), nx23 = widePlanes(NX.z, NX.w, r.ix, anx);
-    const WidePair ny01 = widePlanes(NY.x, NY.y, r.iy, any), ny23 = widePlanes(NY.z, NY.w, r.iy, any);
-    const WidePair nz01 = widePlanes(NZ.x, NZ.y, r.iz, anz), nz23 = widePlanes(NZ.z, NZ.w, r.iz, anz);
-    const WidePair fx01 = widePlanes(FX.x, FX.y, r.ix, afx), fx23 = widePlanes(FX.z, FX.w, r.ix, afx);
-    const WidePair fy01 = widePlanes(FY.x, FY.y, r.iy, afy), fy23 = widePlanes(FY.z, FY.w, r.iy, afy);
-    const WidePair fz01 = widePlanes(FZ.x, FZ.y, r.iz, afz), fz23 = widePlanes(FZ.z, FZ.w, r.iz, afz);
-    const float inf = __builtin_inff();
-    // where the ray enters each child's box, +inf if it does not pass it within `bound`
-    const auto enters = [&](float tnx, float tny, float tnz, float tfx, float tfy, float tfz) {
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bound)) * 1.0000004f;
-        return tn <= tf ? tn : inf;
-    };
-    float d0 = enters(nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x), d1 = enters(nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y);
-    float d2 = enters(nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x), d3 = enters(nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y);
-    int c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-    if constexpr (ORDERED) {
-        // nearest first: a five-exchange sorting network over (distance, child) pairs, misses (+inf) last
-#define RTX_WIDE_ORDER(a, b)                                              \
-    {                                                                     \
-        const bool swap_ = d##b < d##a;                                   \
-        const float lo_ = fminf(d##a, d##b), hi_ = fmaxf(d##a, d##b);     \
-        const int cl_ = swap_ ? c##b : c##a, ch_ = swap_ ? c##a : c##b;   \
-        d##a = lo_, d##b = hi_, c##a = cl_, c##b = ch_;                   \
-    }
-        RTX_WIDE_ORDER(0, 1) RTX_WIDE_ORDER(2, 3) RTX_WIDE_ORDER(0, 2) RTX_WIDE_ORDER(1, 3) RTX_WIDE_ORDER(1, 2)
-#undef RTX_WIDE_ORDER
-    }
-    const bool h0 = d0 < inf, h1 = d1 < inf, h2 = d2 < inf, h3 = d3 < inf;
-#ifdef RTX_PROBE_SP
-    atomicAdd(&g_sp_hist[sp < 63 ? sp : 63], 1u);
-#endif
-    // slot 0 (the nearest child after the sort) next, the others onto the stack, farthest first
-    if (__builtin_expect(sp + 2 < stack.cap, 1)) {
-        stack.lds[sp * stack.stride] = c3;
-        sp += h3 ? 1 : 0;
-        stack.lds[sp * stack.stride] = c2;
-        sp += h2 ? 1 : 0;
-        stack.lds[sp * stack.stride] = c1;
-        sp += h1 ? 1 : 0;
-    } else {
-        stackStore(stack, sp, c3);
-        sp += h3 ? 1 : 0;
-        stackStore(stack, sp, c2);
-        sp += h2 ? 1 : 0;
-        stackStore(stack, sp, c1);
-        sp += h1 ? 1 : 0;
-    }
-    if (h0) return c0;
-    return stackPop(stack, sp);
-}
-
-template <bool STATS, bool ORDERED = true>
+template <bool STATS>
 RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
-                           const LaneStack &stack, LaneCounters<STATS> &lc) {
-    const WideRay wr = wideRay(inv);
-    const float ox = -orig.x * wr.ix, oy = -orig.y * wr.iy, oz = -orig.z * wr.iz;
+                           int *stack, int stride, LaneCounters<STATS> &lc) {
+    // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
+    // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
+    // accept is never culled by rounding here.
+    const float ix = inv.x, iy = inv.y, iz = inv.z;  // clamped reciprocals: no inf - inf below
+    const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
     // Two alternating phases, each a loop the whole wave runs together: descend through inner
     // nodes until this lane holds a leaf (lanes that found theirs idle until the rest have), then
     // one triangle test for every lane that holds one.  `cur` >= 0 is an inner node, < 0 is leaf
     // ~cur, kDone means the stack ran dry.  A single-triangle mesh has an inner root with one leaf.
-    constexpr int kDone = kWalkDone;
+    constexpr int kDone = (int)0x80000000;
     int sp = 0;
     int cur = 0;
     int best_key = kNoCell;  // order in which the reference's walk reaches best_tri
     for (;;) {
         while (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(s.bvh + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
             RTX_COUNT(CNT_NODE_TESTS);
             if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            cur = wideNodeTrip<ORDERED>(s.bvh, cur, wr, ox, oy, oz, ox, oy, oz, best_t, stack, sp);
+            float tnL, tfL, tnR, tfR;
+            {
+                float t0 = __builtin_fmaf(a.x, ix, ox), t1 = __builtin_fmaf(a.w, ix, ox);
+                float t2 = __builtin_fmaf(a.y, iy, oy), t3 = __builtin_fmaf(b.x, iy, oy);
+                float t4 = __builtin_fmaf(a.z, iz, oz), t5 = __builtin_fmaf(b.y, iz, oz);
+                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+            }
+            {
+                float t0 = __builtin_fmaf(b.z, ix, ox), t1 = __builtin_fmaf(c.y, ix, ox);
+                float t2 = __builtin_fmaf(b.w, iy, oy), t3 = __builtin_fmaf(c.z, iy, oy);
+                float t4 = __builtin_fmaf(c.x, iz, oz), t5 = __builtin_fmaf(c.w, iz, oz);
+                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+            }
+            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
+            // near child (or the only one hit) next, the far one onto the stack; written without
+            // nested branches: the store is harmless when nothing is pushed (the slot is free)
+            const bool both = hitL && hitR;
+            const bool leftNext = hitL && (!hitR || tnL <= tnR);
+            stack[sp * stride] = leftNext ? ch.y : ch.x;
+            sp += both ? 1 : 0;
+            cur = leftNext ? ch.x : ch.y;
+            if (!(hitL || hitR)) {
+                cur = kDone;
+                if (sp > 0) {
+                    --sp;
+                    cur = stack[sp * stride];
+                }
+            }
         }
         // the lanes that hold a leaf test it, and go on testing while what they pop is a leaf again
         while (cur != kDone && cur < 0) {
@@ -271,7 +179,11 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
                     if (t < t_exit) return true;
                 }
             }
-            cur = stackPop(stack, sp);
+            cur = kDone;
+            if (sp > 0) {
+                --sp;
+                cur = stack[sp * stride];
+            }
         }
         if (cur == kDone) break;
     }
@@ -279,8 +191,8 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
 }
 
 // ---------------------------------------------------------------------------------------------
-// Spheres beyond the LDS staging limit: spheresIntersect (src/SceneObjects.cpp:289-302) over a four-wide
-// tree of the spheres' boxes instead of the whole list.  The test at a leaf is the reference's own
+// Spheres beyond the LDS staging limit: spheresIntersect (src/SceneObjects.cpp:289-302) over a BVH2
+// of the spheres' boxes instead of the whole list.  The test at a leaf is the reference's own
 // (sphereHit); the winner is the nearest sphere and, among equal distances, the one that comes
 // first in the list, which is what the reference's loop with its strict `curDist < spheresDist`
 // keeps.
@@ -307,45 +219,67 @@ RTX_DEV float sphereReach(const DevScene &s, V3 orig, float t_exit) {
     return t_exit > 0.0f ? fminf(reach, 1.02f * (t_exit + s.sphere_rmax)) : reach;
 }
 
-template <bool STATS, bool ORDERED = true>
+template <bool STATS>
 RTX_DEV void sphereWalk(const DevScene &s, V3 orig, V3 dir, V3 inv, float reach, float t_exit, float &minDist, int &index,
-                        const LaneStack &stack, LaneCounters<STATS> &lc) {
-    const WideRay wr = wideRay(inv);
-    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    float bound, anx, any, anz, afx, afy, afz;
-    // Plane distances of the widened boxes: (lo - delta - o) * inv = lo * inv + a, (hi + delta - o) * inv = hi * inv + b.
-    // The plane a ray meets first on an axis is lo for a positive direction, hi for a negative one.
-    const auto widen = [&]() {
-        bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));  // no candidate's closest approach lies beyond
-        const float delta = kSphereSlack * (bound + s.sphere_rmax);
-        const float ax = -(orig.x + delta) * wr.ix, bx = -(orig.x - delta) * wr.ix;
-        const float ay = -(orig.y + delta) * wr.iy, by = -(orig.y - delta) * wr.iy;
-        const float az = -(orig.z + delta) * wr.iz, bz = -(orig.z - delta) * wr.iz;
-        anx = sx ? bx : ax, afx = sx ? ax : bx;
-        any = sy ? by : ay, afy = sy ? ay : by;
-        anz = sz ? bz : az, afz = sz ? az : bz;
-    };
-    widen();
+                        int *stack, int stride, LaneCounters<STATS> &lc) {
+    const float ix = inv.x, iy = inv.y, iz = inv.z;
+    float bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));  // no candidate's closest approach lies beyond
+    float delta = kSphereSlack * (bound + s.sphere_rmax);
+    // plane distances of the widened boxes: (lo - delta - o) * inv = lo * inv + a, (hi + delta - o) * inv = hi * inv + b
+    float ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
+    float ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
+    float az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
     int sp = 0;
     int cur = 0;  // >= 0 inner node, < 0 sphere ~cur
-    while (cur != kWalkDone) {
+    for (;;) {
         if (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(s.sphere_bvh + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
             RTX_COUNT(CNT_NODE_TESTS);
             if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            cur = wideNodeTrip<ORDERED>(s.sphere_bvh, cur, wr, anx, any, anz, afx, afy, afz, bound, stack, sp);
-            continue;
+            float tnL, tfL, tnR, tfR;
+            {
+                float t0 = __builtin_fmaf(a.x, ix, ax), t1 = __builtin_fmaf(a.w, ix, bx);
+                float t2 = __builtin_fmaf(a.y, iy, ay), t3 = __builtin_fmaf(b.x, iy, by);
+                float t4 = __builtin_fmaf(a.z, iz, az), t5 = __builtin_fmaf(b.y, iz, bz);
+                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+            }
+            {
+                float t0 = __builtin_fmaf(b.z, ix, ax), t1 = __builtin_fmaf(c.y, ix, bx);
+                float t2 = __builtin_fmaf(b.w, iy, ay), t3 = __builtin_fmaf(c.z, iy, by);
+                float t4 = __builtin_fmaf(c.x, iz, az), t5 = __builtin_fmaf(c.w, iz, bz);
+                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+            }
+            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
+            const bool both = hitL && hitR;
+            const bool leftNext = hitL && (!hitR || tnL <= tnR);
+            stack[sp * stride] = leftNext ? ch.y : ch.x;
+            sp += both ? 1 : 0;
+            cur = leftNext ? ch.x : ch.y;
+            if (hitL || hitR) continue;
+        } else {
+            const int i = ~cur;
+            const float4 sph = s.spheres[i];
+            RTX_COUNT(CNT_SPHERE_TESTS);
+            float curDist = 0.0f;
+            if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) &&
+                (curDist < minDist || (curDist == minDist && i < index))) {
+                minDist = curDist;
+                index = i;
+                if (curDist < t_exit) return;
+                bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));
+                delta = kSphereSlack * (bound + s.sphere_rmax);
+                ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
+                ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
+                az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
+            }
         }
-        const int i = ~cur;
-        const float4 sph = s.spheres[i];
-        RTX_COUNT(CNT_SPHERE_TESTS);
-        float curDist = 0.0f;
-        if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
-            minDist = curDist;
-            index = i;
-            if (curDist < t_exit) return;
-            widen();
-        }
-        cur = stackPop(stack, sp);
+        if (sp == 0) return;
+        --sp;
+        cur = stack[sp * stride];
     }
 }
 
@@ -370,8 +304,8 @@ struct CastState {
 
 // WIDE = the general build of the kernels: sphere sets beyond the LDS staging limit (behind their
 // BVH), several samples per pixel.  The default build leaves both out, the code and the registers.
-template <bool STATS, bool WIDE, bool ANYHIT = false>
-RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, float t_exit, CastState &cs, const LaneStack &stack,
+template <bool STATS, bool WIDE>
+RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, float t_exit, CastState &cs, int *stack, int stride,
                        LaneCounters<STATS> &lc) {
     float minDist = kFltMax;
     int kind = 0, index = -1;
@@ -386,7 +320,7 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
             const float lo[3] = {q.object_bounds[0] - delta, q.object_bounds[1] - delta, q.object_bounds[2] - delta};
             const float hi[3] = {q.object_bounds[3] + delta, q.object_bounds[4] + delta, q.object_bounds[5] + delta};
             if (!slabMaybe(lo, hi, orig, inv)) return false;
-            sphereWalk<STATS, !ANYHIT>(s, orig, dir, inv, reach, t_exit, minDist, index, stack, lc);
+            sphereWalk<STATS>(s, orig, dir, inv, reach, t_exit, minDist, index, stack, stride, lc);
             if (index >= 0) kind = 1;
             walked = true;
         }
@@ -451,11 +385,11 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     return s.n_mesh_tris > 0 && !(minDist < t_exit) && meshGate<STATS>(s, orig, dir, inv, lc);
 }
 
-template <bool STATS, bool ANYHIT = false>
-RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastState &cs, const LaneStack &stack, LaneCounters<STATS> &lc) {
+template <bool STATS>
+RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastState &cs, int *stack, int stride, LaneCounters<STATS> &lc) {
     int tri = -1;
     float t = cs.minDist;
-    meshIntersect<STATS, !ANYHIT>(s, orig, dir, safeInverse(dir), t, tri, t_exit, stack, lc);
+    meshIntersect<STATS>(s, orig, dir, safeInverse(dir), t, tri, t_exit, stack, stride, lc);
     if (tri >= 0) cs.minDist = t, cs.kind = 4, cs.index = tri;
 }
 
@@ -569,12 +503,11 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     return minDist < s.far_clip;
 }
 
-// ANYHIT: every ray of the launch is a shadow ray (the walks then skip ordering the children by distance)
-template <bool STATS, bool WIDE = false, bool ANYHIT = false>
+template <bool STATS, bool WIDE = false>
 RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, Hit &h,
-                            float &min_dist, const LaneStack &stack, LaneCounters<STATS> &lc) {
+                            float &min_dist, int *stack, int stride, LaneCounters<STATS> &lc) {
     CastState cs;
-    if (castBegin<STATS, WIDE, ANYHIT>(s, q, orig, dir, t_exit, cs, stack, lc)) castMesh<STATS, ANYHIT>(s, orig, dir, t_exit, cs, stack, lc);
+    if (castBegin<STATS, WIDE>(s, q, orig, dir, t_exit, cs, stack, stride, lc)) castMesh<STATS>(s, orig, dir, t_exit, cs, stack, stride, lc);
     return castEnd<STATS, WIDE>(s, q, orig, dir, shadow, t_exit, cs, h, min_dist, lc);
 }
 
@@ -938,7 +871,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
 }
 
 template <bool STATS, bool WIDE = false>
-RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, const LaneStack &stack, LaneCounters<STATS> &lc) {
+RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int depth, int *stack, int stride, LaneCounters<STATS> &lc) {
     PathState st;
     FrameSpill spill;  // all frames in scratch memory here, the rest of the state in registers
     FrameStack frames = frameStack(spill);
@@ -950,7 +883,7 @@ RTX_DEV V3 traceRay(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, int
         float md = 0.0f;
         if (pathCasts(st, -1)) {
             pathCountRay<STATS>(st, -1, lc);
-            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, lc);
+            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, stride, lc);
         }
         if (pathConsume<STATS, WIDE>(s, q, st, frames, hit, h, md, -1, color, lc)) return color;
     }

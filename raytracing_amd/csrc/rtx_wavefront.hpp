@@ -200,18 +200,14 @@ RTX_DEV bool wfSamplePixel(const DevFrame &fr, const WfStrip &strip, unsigned i,
 // The traversal stacks live in dynamic LDS, sized by the launch for the depth of the scene's trees
 // (stack entries x kBlock ints): the less of it, the more workgroups a CU holds.
 extern __shared__ int s_wf_stack[];
-#ifndef RTX_WF_WIDE_WAVES
-#define RTX_WF_WIDE_WAVES 5
-#endif
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_WIDE_WAVES : 4) void k_wf_trace(DevScene s, DevCamera cam, DevFrame fr, WfStrip strip, WfArgs a,
+__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_trace(DevScene s, DevCamera cam, DevFrame fr, WfStrip strip, WfArgs a,
                                                                     Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
     loadSmallScene(q, s);
-    int stack_over[kWalkStack];
-    const LaneStack stack{s_wf_stack + threadIdx.x, kBlock, s.stack_cap, stack_over};
+    int *stack = s_wf_stack + threadIdx.x;
     const int level = a.level, depth = fr.depth - level;  // remaining depth of this level's traceRay calls
     const unsigned n_samples = strip.n_tiles * 64u * (unsigned)fr.spp;
     unsigned n_chunks = (n_samples + kWfChunk - 1) / kWfChunk;  // level 0: the strip's samples, no list
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_WIDE_WAVES : 4) v
         Hit h;
         float md = 0.0f;
         bool hit = false;
-        if (casts) hit = sceneIntersect<STATS, WIDE>(s, q, orig, dir, false, -1.0f, h, md, stack, lc);
+        if (casts) hit = sceneIntersect<STATS, WIDE>(s, q, orig, dir, false, -1.0f, h, md, stack, kBlock, lc);
         if (valid && !hit) {
             RTX_COUNT(CNT_SKY);
             wfDeliver(a.parent, level, link, skyColor(s, dir));
@@ -309,12 +305,11 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_WIDE_WAVES : 4) v
 }
 
 template <bool STATS, bool WIDE>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_WIDE_WAVES : 4) void k_wf_shadow(DevScene s, WfArgs a, Counters *counters) {
+__global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(DevScene s, WfArgs a, Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
     loadSmallScene(q, s);
-    int stack_over[kWalkStack];
-    const LaneStack stack{s_wf_stack + threadIdx.x, kBlock, s.stack_cap, stack_over};
+    int *stack = s_wf_stack + threadIdx.x;
     wfChunksLoad(ch, a.shadows);
     const unsigned n_chunks = ch.n_chunks;
     LaneCounters<STATS> lc;
@@ -341,7 +336,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_WIDE_WAVES : 4) v
         RTX_COUNT(CNT_SHADOW);
         Hit h;
         float md = 0.0f;
-        const bool hit = sceneIntersect<STATS, WIDE, true>(s, q, st.orig, st.dir, true, st.t_exit, h, md, stack, lc);
+        const bool hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, true, st.t_exit, h, md, stack, kBlock, lc);
         if (pathShadowed(st, hit, md)) atomicOr(reinterpret_cast<unsigned *>(a.fat + 4 * (size_t)node + 1) + 3, 1u << li);
     }
     flushCounters<STATS>(lc, counters);

@@ -159,24 +159,3 @@ def test_every_frame_writes_every_pixel_with_four_samples(hip, oracle_backend, t
         ctx.render_device(cam, Frame(w, h, 3, 0, 1), buf.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(buf.cpu().numpy().reshape(h, w, 3), want)
-
-
-@pytest.mark.parametrize("lds_entries", [1, 2, 5])
-@pytest.mark.parametrize("pipeline", [0, 1])
-def test_traversal_stack_overflow_into_scratch_memory(hip, oracle_backend, textures, lds_entries, pipeline):
-    """The walks keep only the first entries of a lane's traversal stack in LDS and push what goes beyond them to
-    scratch memory.  With one, two or five entries in LDS nearly every walk of the mesh's and of the spheres' tree
-    overflows: same hit records bit for bit, same frames byte for byte, on both pipelines."""
-    from raytracing_amd.rtx import OPT_LDS_STACK, OPT_PIPELINE
-    c, r, m = _sphere_cloud(300, 300)
-    rays = [_rays_at(c, 20000, 3, 3.0), _rays_at(c, 20000, 4, 400.0)]
-    out = []
-    for b in (oracle_backend, hip):
-        ctx = make_default_context(b, textures, options=[(OPT_LDS_STACK, lds_entries), (OPT_PIPELINE, pipeline)], commit=False)
-        ctx.set_spheres(c, r, m)
-        ctx.commit()
-        out.append([ctx.intersect_rays(o, d) for o, d in rays] + [ctx.trace_rays(*rays[0], depth=3)]
-                   + [ctx.render(b.default_camera(), 320, 200, 4)])
-    for a, g in zip(out[0][:3], out[1][:3]):
-        assert np.array_equal(a.view(np.uint32), g.view(np.uint32))
-    assert np.array_equal(out[0][3], out[1][3])
