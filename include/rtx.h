@@ -23,6 +23,7 @@
 #ifndef RTX_H
 #define RTX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -135,6 +136,13 @@ enum rtx_option {
                                  ray counts; level by level has no schedule feedback and no quad mode */
     RTX_OPT_PIPELINE_BUDGET_MB = 11, /* MiB of device memory the arrays of RTX_OPT_PIPELINE = 1 may take (default
                                  16384); a frame that needs more is traced in strips of tiles      */
+    RTX_OPT_PIN_OUTPUT = 12,  /* 0/1 (default 0): rtx_render / rtx_group_render may page-lock the caller's output buffer
+                                 (hipHostRegister) and keep it so while the same buffer keeps being passed: the frame
+                                 then leaves the GPU at the speed of the link instead of through the runtime's pageable
+                                 staging (three times as fast for a 3840x2160 frame).  The caller promises that the
+                                 buffer stays allocated until it passes another one, clears the option or destroys the
+                                 context.  A buffer that is page-locked already (rtx_host_alloc, hipHostMalloc) gets the
+                                 fast copy without this option                                                    */
     RTX_OPT_MESH_GRID = 5     /* 0/1 (default 1), before rtx_commit: 1 = a mesh triangle is hit only
                                  by rays that pass one of the 7x7x7 grid cells holding its vertices,
                                  as the reference's BoundingBox walk has it (src/SceneObjects.cpp:
@@ -195,10 +203,22 @@ int rtx_commit(rtx_ctx *ctx);
  * bgr_out: host buffer of rtx_frame_rows(frame) * width * 3 bytes.  stats may be NULL. */
 int rtx_render(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, unsigned char *bgr_out,
                rtx_stats *stats);
+/* Page-locked host memory for rtx_render's / rtx_group_render's output (NULL when there is none to be had): a frame is
+ * copied into it at the speed of the link.  No counterpart in the reference (its pixel store is plain memory,
+ * include/bitmap_image.hpp:83-92); the oracle returns ordinary memory. */
+void *rtx_host_alloc(size_t bytes);
+void rtx_host_free(void *p);
 /* Same, for callers that own device memory (a torch tensor, an RCCL send buffer): d_bgr_out is a
  * device pointer on the context's GPU, hip_stream a hipStream_t (NULL = the context's own stream).
- * The call only enqueues work; the caller synchronises the stream.  The oracle has no device and
- * returns RTX_E_STATE. */
+ * The call only enqueues work; the caller synchronises the stream.  One render of a context at a time: the
+ * next call on a context must follow the previous one in stream order (same stream, or after the caller has
+ * waited).  Exceptions to "only enqueues": the first frame of a larger size than the context has seen
+ * allocates its scheduling memory after a device-wide wait, and so does the level-by-level pipeline
+ * (RTX_OPT_PIPELINE) when its arrays have to grow -- it keeps the largest block it ever needed, stays within
+ * RTX_OPT_PIPELINE_BUDGET_MB and three quarters of the GPU's free memory by tracing in strips, and hands the frame
+ * to the one-kernel pipeline when not even one tile's arrays fit.  rtx_render_device_noalloc never allocates.
+ * A stream that is being captured into a HIP graph gets no timing events (rtx_get_stats then reports no
+ * kernel time).  The oracle has no device and returns RTX_E_STATE. */
 int rtx_render_device(rtx_ctx *ctx, const rtx_camera *cam, const rtx_frame *frame, void *d_bgr_out,
                       void *hip_stream);
 /* rtx_render_device for callers that cannot allocate device memory: code under HIP graph capture,
@@ -243,10 +263,25 @@ void rtx_group_destroy(rtx_group *group);
 int rtx_group_size(const rtx_group *group);
 rtx_ctx *rtx_group_ctx(rtx_group *group, int rank);
 int rtx_group_commit(rtx_group *group);
+/* rtx_set_option on every rank's context; RTX_OPT_PIN_OUTPUT applies to rtx_group_render's output buffer. */
+int rtx_group_set_option(rtx_group *group, int option, uint32_t value);
 /* bgr_out: host buffer of height * width * 3 bytes; stats (may be NULL): ray counts summed over the ranks,
- * kernel_ms the slowest rank's. */
+ * kernel_ms the slowest rank's.  Waits for the frame. */
 int rtx_group_render(rtx_group *group, const rtx_camera *cam, int width, int height, int depth,
                      unsigned char *bgr_out, rtx_stats *stats);
+/* The same frame left in the memory of the root's GPU (device_ids[0]): *d_frame_out points at height * width * 3
+ * bytes there.  The call only enqueues -- renders on the ranks' streams, the exchange and the de-interleave on a
+ * stream per GPU of their own -- and returns; the work that completes the frame is ordered on
+ * rtx_group_root_stream(group) (a hipStream_t on the root's GPU): enqueue the consumer there, or record an event
+ * there, or call rtx_group_wait.  All buffers exist twice and alternate: the exchange of one frame runs under the
+ * render of the next, and a frame stays valid until the call after the next one.  Nothing is allocated after the
+ * first frame of a size.  replaces: src/Scene.cpp:214-227 for a caller that keeps the frame on the GPU (display,
+ * encoder); the oracle has no device and returns RTX_E_STATE. */
+int rtx_group_render_device(rtx_group *group, const rtx_camera *cam, int width, int height, int depth,
+                            void **d_frame_out);
+void *rtx_group_root_stream(rtx_group *group);
+/* waits for everything the group has enqueued */
+int rtx_group_wait(rtx_group *group);
 const char *rtx_group_last_error(void);
 
 /* Traces caller-supplied rays through Scene::traceRay semantics (src/Scene.cpp:83-106) and

@@ -595,6 +595,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_QUAD: break;
         case RTX_OPT_PIPELINE: break;  // one loop here
         case RTX_OPT_PIPELINE_BUDGET_MB: break;
+        case RTX_OPT_PIN_OUTPUT: break;  // no device to copy from
         case RTX_OPT_SPP:
             if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
             c->spp = (int)value;
@@ -892,6 +893,17 @@ int rtx_group_render(rtx_group *g, const rtx_camera *cam, int width, int height,
     return RTX_OK;
 }
 const char *rtx_group_last_error(void) { return rtx_last_error(); }
+int rtx_group_set_option(rtx_group *g, int option, uint32_t value) {
+    if (!g) return fail(RTX_E_INVALID, "null group");
+    for (rtx_ctx *c : g->ctx)
+        if (int e = rtx_set_option(c, option, value)) return e;
+    return RTX_OK;
+}
+int rtx_group_render_device(rtx_group *, const rtx_camera *, int, int, int, void **) { return fail(RTX_E_STATE, "the CPU oracle has no device memory"); }
+void *rtx_group_root_stream(rtx_group *) { return nullptr; }
+int rtx_group_wait(rtx_group *g) { return g ? RTX_OK : fail(RTX_E_INVALID, "null group"); }
+void *rtx_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void rtx_host_free(void *p) { free(p); }
 
 int rtx_deinterleave_rows_device(rtx_ctx *, const void *, int, int, int, int, void *, void *) {
     return fail(RTX_E_STATE, "the CPU oracle has no device path");

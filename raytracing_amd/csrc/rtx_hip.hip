@@ -20,6 +20,7 @@
 #include "sah_build.hpp"
 #include "rtx_device.hpp"
 #include "rtx_trace.hpp"
+#include "host_copy.hpp"
 
 using namespace rtx;
 
@@ -784,6 +785,7 @@ struct rtx_ctx {
     size_t wf_budget = (size_t)16 << 30;    // bytes the pipeline's arrays may take
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
+    HostStage stage;                        // rtx_render's way to the caller's host buffer (RTX_OPT_PIN_OUTPUT)
 };
 
 namespace {
@@ -1056,7 +1058,11 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     fr.lds_frames = std::max(0, std::min(f->depth - 1, c->lds_frame_slots[variant]));  // a frame of depth d has at most d - 1 nodes waiting
     const long long want = (4 * n_tiles + kBlock / 64 - 1) / (kBlock / 64);  // room for the quarters of quad tiles
     const unsigned blocks = (unsigned)(want < resident ? want : resident);
-    HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
+    // (a stream that is being captured into a graph takes no timing events: rtx_get_stats could not wait for them)
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess) (void)hipGetLastError(), capture = hipStreamCaptureStatusNone;
+    const bool timed = capture == hipStreamCaptureStatusNone;
+    if (timed) HIP_OR_FAIL(hipEventRecord(c->ev0, stream));
     if (c->stats) HIP_OR_FAIL(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), stream));
     unsigned *const heads = m.heads + (ss.heads_flip ? kQueues * kHeadStride : 0u);
     unsigned *const heads_next = m.heads + (ss.heads_flip ? 0u : kQueues * kHeadStride);
@@ -1085,8 +1091,8 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
     HIP_OR_FAIL(hipGetLastError());
     ss.heads_flip = !ss.heads_flip;  // only now: a launch that failed has cleared nothing
     ss.cost_view.set(cam, f), ss.have_cost = true;
-    HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
-    c->timed = true;
+    if (timed) HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
     return RTX_OK;
 }
 
@@ -1146,24 +1152,51 @@ WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
     return p;
 }
 
-// Sizes the pipeline's arrays for this frame: whole frame in one strip if that fits the budget.
+// Sizes the pipeline's arrays for this frame: the whole frame in one strip if that fits the budget -- the
+// caller's (RTX_OPT_PIPELINE_BUDGET_MB) or three quarters of what the GPU has free, whichever is less -- otherwise
+// strips of tile rows.  A block that is large enough is kept and carved anew (no allocation, no wait); a larger
+// one is allocated after a device-wide wait, in halved strips if the GPU refuses.  RTX_E_NOMEM when not even the
+// arrays of a single tile fit: the caller then renders with the one-kernel pipeline.
 int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
     WfMem &w = c->wf;
     const int nl = c->dev.n_lights;
     const size_t unit = (size_t)64 * spp;  // samples of one tile
+    const size_t slack = 256 * (4 * kWfLevels + 8);  // alignment of the carved arrays
+    size_t budget = c->wf_budget;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (free_b + w.block_bytes) / 4 * 3);
+        else (void)hipGetLastError();
+        budget = std::max(budget, w.block_bytes);  // what is already there may always be used
+    }
     size_t strip = (frame_samples + unit - 1) / unit * unit;
     WfPlan plan = wavefrontPlan(D, nl, strip);
-    while ((plan.bytes > c->wf_budget || !plan.fits) && strip > unit) {  // halve until it fits
-        strip = std::max(unit, strip / 2 / unit * unit);
-        plan = wavefrontPlan(D, nl, strip);
+    for (;;) {
+        while ((plan.bytes + slack > budget || !plan.fits) && strip > unit) {  // halve until it fits
+            strip = std::max(unit, strip / 2 / unit * unit);
+            plan = wavefrontPlan(D, nl, strip);
+        }
+        if (plan.bytes + slack > budget || !plan.fits) return fail(RTX_E_NOMEM, "the level-by-level arrays of a single tile do not fit the memory budget");
+        if (w.block && w.block_bytes >= plan.bytes + slack) break;
+        HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old block
+        (void)hipFree(w.block);
+        w = WfMem();
+        const hipError_t e = hipMalloc(&w.block, plan.bytes + slack);
+        if (e == hipSuccess) {
+            w.block_bytes = plan.bytes + slack;
+            break;
+        }
+        (void)hipGetLastError();
+        w.block = nullptr;
+        if (e != hipErrorOutOfMemory) return failHip(e, "level-by-level arrays");
+        budget = (plan.bytes + slack) / 2;  // the GPU is fuller than it said: try half
+        if (strip <= unit) return fail(RTX_E_NOMEM, "no device memory for the level-by-level arrays of a single tile");
     }
-    if (w.block && w.depth == D && w.n_lights == nl && w.strip_samples == strip) return RTX_OK;
-    HIP_OR_FAIL(hipDeviceSynchronize());  // an earlier launch may still use the old block
-    (void)hipFree(w.block);
-    w = WfMem();
-    HIP_OR_FAIL(hipMalloc(&w.block, plan.bytes + 256 * (4 * kWfLevels + 8)));
-    w.block_bytes = plan.bytes + 256 * (4 * kWfLevels + 8), w.strip_samples = strip, w.depth = D, w.n_lights = nl;
+    if (w.depth == D && w.n_lights == nl && w.strip_samples == strip) return RTX_OK;  // carved for this plan already
+    w.strip_samples = strip, w.depth = D, w.n_lights = nl;
     w.plan = plan;
+    for (int l = 0; l <= kWfLevels; ++l) w.ray_o[l] = w.ray_d[l] = w.thin[l] = nullptr;
+    w.fat = nullptr, w.shadow_q = nullptr;
     unsigned char *p = static_cast<unsigned char *>(w.block);
     auto take = [&](size_t n) {
         unsigned char *q = p;
@@ -1185,7 +1218,10 @@ int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
         w.fat = reinterpret_cast<float4 *>(take(fat_entries * 4 * sizeof(float4)));
         w.shadow_q = reinterpret_cast<unsigned *>(take(fat_entries * (size_t)(nl > 0 ? nl : 1) * sizeof(unsigned)));
     }
-    if ((size_t)(p - static_cast<unsigned char *>(w.block)) > w.block_bytes) return fail(RTX_E_NOMEM, "wavefront arrays overrun their block");
+    if ((size_t)(p - static_cast<unsigned char *>(w.block)) > w.block_bytes) {
+        w.depth = -1;
+        return fail(RTX_E_NOMEM, "level-by-level arrays overrun their block");
+    }
     return RTX_OK;
 }
 
@@ -1307,6 +1343,7 @@ void rtx_destroy(rtx_ctx *c) {
     (void)hipFree(c->sched.entries);
     (void)hipFree(c->wf.block);
     (void)hipFree(c->d_frame);
+    c->stage.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1345,6 +1382,10 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
             if (value > 3) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 surface-area heuristic on the GPU, 1 Morton order on the GPU, 2 surface-area heuristic on the host, 3 clustering on the GPU");
             c->bvh_builder = (int)value;
+            break;
+        case RTX_OPT_PIN_OUTPUT:
+            c->stage.may_pin = value != 0;
+            if (!c->stage.may_pin) c->stage.release();
             break;
         case RTX_OPT_MESH_GRID:
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_MESH_GRID must be set before rtx_commit");
@@ -1693,14 +1734,14 @@ int rtx_render(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned c
         HIP_OR_FAIL(hipMalloc((void **)&c->d_frame, bytes));
         c->d_frame_bytes = bytes;
     }
-    if (byLevels(c)) {
-        if (int e = launchWavefront(c, cam, f, c->d_frame, c->stream)) return e;
-    } else {
+    int levels = byLevels(c) ? launchWavefront(c, cam, f, c->d_frame, c->stream) : RTX_E_NOMEM;
+    if (levels != RTX_OK && (levels != RTX_E_NOMEM || c->pipeline == 1)) return levels;
+    if (levels == RTX_E_NOMEM) {  // the one-kernel pipeline: chosen, or no memory for the level-by-level arrays
         if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
         if (int e = launchRender(c, cam, f, c->d_frame, c->stream, c->sched, c->sched_state, c->feedback != 0)) return e;
     }
-    if (bytes) HIP_OR_FAIL(hipMemcpyAsync(bgr_out, c->d_frame, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_OR_FAIL(hipStreamSynchronize(c->stream));
+    std::string why;
+    if (!c->stage.toHost(bgr_out, c->d_frame, bytes, c->stream, &why)) return fail(RTX_E_DEVICE, why);
     if (stats) return rtx_get_stats(c, stats);
     return RTX_OK;
 }
@@ -1711,7 +1752,10 @@ int rtx_render_device(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, voi
     if (int e = bind(c)) return e;
     const int rows = rtx_frame_rows(f);
     hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    if (byLevels(c)) return launchWavefront(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream);
+    if (byLevels(c)) {
+        const int e = launchWavefront(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream);
+        if (e != RTX_E_NOMEM || c->pipeline == 1) return e;  // (no memory for the arrays of even one tile: the one-kernel pipeline)
+    }
     if (int e = scheduleBuffers(c, (size_t)((f->width + 7) / 8) * (size_t)((rows + 7) / 8))) return e;
     return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream, c->sched, c->sched_state, c->feedback != 0);
 }
@@ -1745,6 +1789,19 @@ int rtx_render_device_noalloc(rtx_ctx *c, const rtx_camera *cam, const rtx_frame
     HIP_OR_FAIL(hipMemsetAsync(m.heads, 0, kHeadWords * sizeof(unsigned), stream));
     SchedState fresh;
     return launchRender(c, cam, f, static_cast<unsigned char *>(d_bgr_out), stream, m, fresh, false);
+}
+
+void *rtx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void rtx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rtx_get_stats(rtx_ctx *c, rtx_stats *o) {

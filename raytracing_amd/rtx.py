@@ -17,7 +17,7 @@ HIP_FAST_LIB_PATH = os.path.join(_PKG, "librtx_hip_fast.so")  # the tolerance bu
 ASSETS_DIR = os.path.join(os.path.dirname(_PKG), "assets")
 
 MASK_SPHERES, MASK_CUBES, MASK_TRIANGLES, MASK_MODEL, MASK_ISLANDS, MASK_ALL = 1, 2, 4, 8, 16, 31
-OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID, OPT_BVH_BUILDER, OPT_SCHEDULE_FEEDBACK, OPT_QUAD, OPT_SPP, OPT_PIPELINE, OPT_PIPELINE_BUDGET_MB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID, OPT_BVH_BUILDER, OPT_SCHEDULE_FEEDBACK, OPT_QUAD, OPT_SPP, OPT_PIPELINE, OPT_PIPELINE_BUDGET_MB, OPT_PIN_OUTPUT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 
 class RtxError(RuntimeError):
@@ -56,7 +56,8 @@ RTX_SYMBOLS = ["rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_option", 
                "rtx_set_spheres", "rtx_set_boxes", "rtx_set_triangles", "rtx_set_mesh", "rtx_set_islands", "rtx_set_water",
                "rtx_set_envmap", "rtx_commit", "rtx_render", "rtx_render_device", "rtx_render_device_noalloc", "rtx_get_stats", "rtx_frame_rows",
                "rtx_deinterleave_rows_device", "rtx_trace_rays", "rtx_intersect_rays", "rtx_group_create", "rtx_group_destroy",
-               "rtx_group_size", "rtx_group_ctx", "rtx_group_commit", "rtx_group_render", "rtx_group_last_error"]
+               "rtx_group_size", "rtx_group_ctx", "rtx_group_commit", "rtx_group_render", "rtx_group_last_error",
+               "rtx_group_set_option", "rtx_group_render_device", "rtx_group_root_stream", "rtx_group_wait", "rtx_host_alloc", "rtx_host_free"]
 HOST_SYMBOLS = ["rt_default_materials", "rt_material_index", "rt_default_camera", "rt_load_model", "rt_free",
                 "rt_decode_jpeg", "rt_scene_load_default", "rt_scene_load_default_tex", "rt_save_bmp", "rt_main",
                 "rt_host_last_error"]
@@ -92,6 +93,12 @@ _SIGNATURES = {
     "rtx_group_commit": (_i, [_vp]),
     "rtx_group_render": (_i, [_vp, C.POINTER(Camera), _i, _i, _i, _vp, C.POINTER(Stats)]),
     "rtx_group_last_error": (C.c_char_p, []),
+    "rtx_group_set_option": (_i, [_vp, _i, _u32]),
+    "rtx_group_render_device": (_i, [_vp, C.POINTER(Camera), _i, _i, _i, C.POINTER(_vp)]),
+    "rtx_group_root_stream": (_vp, [_vp]),
+    "rtx_group_wait": (_i, [_vp]),
+    "rtx_host_alloc": (_vp, [C.c_size_t]),
+    "rtx_host_free": (None, [_vp]),
     "rt_default_materials": (_i, [_vp]),
     "rt_material_index": (_i, [C.c_char_p]),
     "rt_default_camera": (_i, [C.POINTER(Camera)]),
@@ -171,6 +178,20 @@ class Backend:
         bgr = _u8(bgr)
         h, w = bgr.shape[0], bgr.shape[1]
         self.check(self.lib.rt_save_bmp(bgr.ctypes.data, w, h, os.fsencode(path)))
+
+    def host_array(self, shape):
+        """A uint8 array in page-locked host memory (rtx_host_alloc): rtx_render copies a frame into it at the speed of
+        the link.  Freed when the array (and every view of it) is gone."""
+        n = int(np.prod(shape))
+        p = self.lib.rtx_host_alloc(n)
+        if not p:
+            raise MemoryError("rtx_host_alloc(%d)" % n)
+        buf = (C.c_ubyte * n).from_address(p)
+        lib = self.lib
+        import weakref
+        arr = np.frombuffer(buf, np.uint8).reshape(shape)
+        weakref.finalize(buf, lib.rtx_host_free, p)
+        return arr
 
     # ---- contexts ----
     def create(self, device=0):
@@ -276,10 +297,13 @@ class Context:
     def frame_rows(self, frame):
         return self.lib.rtx_frame_rows(C.byref(frame))
 
-    def render(self, cam, width, height, depth=4, row_first=0, row_step=1, want_stats=False):
+    def render(self, cam, width, height, depth=4, row_first=0, row_step=1, want_stats=False, out=None):
+        """`out`: a (rows, width, 3) uint8 array to render into (e.g. Backend.host_array: page-locked memory)."""
         fr = Frame(width, height, depth, row_first, row_step)
         rows = self.frame_rows(fr)
-        out = np.zeros((rows, width, 3), np.uint8)
+        if out is None:
+            out = np.zeros((rows, width, 3), np.uint8)
+        assert out.shape == (rows, width, 3) and out.dtype == np.uint8 and out.flags.c_contiguous
         st = Stats()
         self._ck(self.lib.rtx_render(self.handle, C.byref(cam), C.byref(fr), out.ctypes.data, C.byref(st)))
         return (out, st) if want_stats else out
@@ -331,8 +355,24 @@ class Group:
     def commit(self):
         self._ck(self.lib.rtx_group_commit(self.handle))
 
-    def render(self, cam, width, height, depth=4, want_stats=False):
-        out = np.zeros((height, width, 3), np.uint8)
+    def set_option(self, option, value):
+        self._ck(self.lib.rtx_group_set_option(self.handle, option, int(value)))
+
+    def render_device(self, cam, width, height, depth=4):
+        """Enqueues a frame and returns the device address (on the root's GPU) where it will be; see rtx.h."""
+        p = _vp()
+        self._ck(self.lib.rtx_group_render_device(self.handle, C.byref(cam), width, height, depth, C.byref(p)))
+        return p.value
+
+    def root_stream(self):
+        return self.lib.rtx_group_root_stream(self.handle)
+
+    def wait(self):
+        self._ck(self.lib.rtx_group_wait(self.handle))
+
+    def render(self, cam, width, height, depth=4, want_stats=False, out=None):
+        if out is None:
+            out = np.zeros((height, width, 3), np.uint8)
         st = Stats()
         self._ck(self.lib.rtx_group_render(self.handle, C.byref(cam), width, height, depth, out.ctypes.data, C.byref(st)))
         return (out, st) if want_stats else out

@@ -97,3 +97,43 @@ def compare_frames(a, b):
 # the tolerance of BASELINE.json's north_star
 PSNR_MIN_DB = 50.0
 WITHIN_ONE_MIN = 0.999
+
+
+class HipRuntime:
+    """The few HIP runtime calls the GPU tests make themselves (ctypes on the runtime the process has loaded)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = lib = C.CDLL("libamdhip64.so")
+        vp = C.c_void_p
+        lib.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
+        lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        lib.hipStreamCreate.argtypes = [C.POINTER(vp)]
+        lib.hipStreamDestroy.argtypes = [vp]
+        lib.hipStreamSynchronize.argtypes = [vp]
+        lib.hipStreamBeginCapture.argtypes = [vp, C.c_int]
+        lib.hipStreamEndCapture.argtypes = [vp, C.POINTER(vp)]
+        lib.hipGraphInstantiate.argtypes = [C.POINTER(vp), vp, vp, vp, C.c_size_t]
+        lib.hipGraphLaunch.argtypes = [vp, vp]
+        lib.hipGraphExecDestroy.argtypes = [vp]
+        lib.hipGraphDestroy.argtypes = [vp]
+        lib.hipDeviceSynchronize.argtypes = []
+
+    def ok(self, code, what):
+        assert code == 0, "%s failed with HIP error %d" % (what, code)
+
+    def to_host(self, device_ptr, shape):
+        out = np.zeros(shape, np.uint8)
+        self.ok(self.lib.hipMemcpy(out.ctypes.data, self.C.c_void_p(device_ptr), out.size, 2), "hipMemcpy")  # 2 = device to host
+        return out
+
+    def free_bytes(self):
+        free, total = self.C.c_size_t(), self.C.c_size_t()
+        self.ok(self.lib.hipMemGetInfo(self.C.byref(free), self.C.byref(total)), "hipMemGetInfo")
+        return free.value
+
+
+@pytest.fixture(scope="session")
+def hip_runtime(hip):
+    return HipRuntime()
