@@ -25,7 +25,13 @@ first place; the default is the line the metric is quoted on): "planes4k" = sphe
 depth 1 (configs[1]), "bunny4k" = the bunny over the water, depth 4 (configs[2]), "8k" = the full scene
 at 7680x4320 (configs[3]), "stress" = 10 000 seeded spheres + the bunny subdivided to 1 271 808
 triangles, 16384x16384, 4 samples per pixel (configs[4], raytracing_amd/scenes.py).  The CPU baseline is
-timed for the 3840x2160 ones.
+one whole frame by the reference's own code for the default-scene workloads, and the oracle on the
+pixel-centre rays of the 256x256 centre crop, extrapolated, for the stress scene (the reference's algorithm
+tests every sphere for every ray: a whole 16384x16384 frame would take days).
+
+--backend group times the C-ABI group (rtx_group_*: one process, a context per device, RCCL send / recv into
+the root, frames left in device memory and pipelined) instead of the one-process-per-GPU path: over the
+first N GPUs of the node, or -- with fewer than N GPUs -- N ranks that share GPU 0.
 
 Prints ONE JSON line on rank 0.
 """
@@ -144,7 +150,8 @@ def reference_baseline(gpu_frame):
     except Exception as e:  # missing library dependencies, a different host ...
         print("reference baseline unavailable: %r" % (e,), file=sys.stderr)
         return None
-    return {"seconds": dt, "cores": cores, "same_bytes_as_gpu_frame": bool(gpu_frame is not None and np.array_equal(frame, gpu_frame))}
+    differing = int((frame != gpu_frame).any(axis=2).sum()) if gpu_frame is not None else None
+    return {"seconds": dt, "cores": cores, "same_bytes_as_gpu_frame": bool(gpu_frame is not None and differing == 0), "differing_pixels": differing}
 
 
 def cpu_baseline(textures, cam_of, gpu_frame=None):
@@ -174,6 +181,9 @@ def cpu_baseline(textures, cam_of, gpu_frame=None):
                       % (rays, ref["seconds"], dt),
             "ms_per_frame": round(ref["seconds"] * 1e3, 1),
             "same_bytes_as_gpu_frame": ref["same_bytes_as_gpu_frame"],
+            # (at 7680x4320 four pixels see two mesh triangles at exactly the same distance, and the reference decides such ties
+            # by the iteration order of an unordered_set of pointers, i.e. by heap addresses: tests/golden/frames.json lists them)
+            "differing_pixels": ref["differing_pixels"],
         }
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
@@ -181,6 +191,44 @@ def cpu_baseline(textures, cam_of, gpu_frame=None):
                   "%d sceneIntersect calls (the reference also traces the zero-weight children the GPU prunes) in %.2f s"
                   % (rays, dt),
         "ms_per_frame": round(dt * step * 1e3, 1),
+    }
+
+
+def cpu_baseline_stress(textures, n_crop=256):
+    """The stress scene on the host cores: the oracle (the reference's algorithm restated: every sphere tested for
+    every ray, the 7x7x7 grid walk over the 1.27 M triangles) on the pixel-centre rays of the n_crop x n_crop centre
+    crop of the frame, extrapolated to the frame's samples."""
+    import numpy as np
+    import oracle
+    from raytracing_amd import scenes
+    from raytracing_amd.rtx import OPT_STATS, Backend, Frame
+    cpu = Backend(oracle.ORACLE_LIB_PATH)
+    ctx = cpu.create()
+    scenes.load_stress_scene(ctx, cpu, textures["water"], textures["sky"])
+    ctx.set_option(OPT_STATS, 1)
+    ctx.commit()
+    cam = cpu.default_camera()
+    r0, c0 = HEIGHT // 2 - n_crop // 2, WIDTH // 2 - n_crop // 2
+    dirs = np.zeros((n_crop, n_crop, 3), np.float32)
+    row = np.zeros((1, WIDTH, 3), np.float32)
+    cpu.lib.orx_primary_dirs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    for k in range(n_crop):
+        fr = Frame(WIDTH, HEIGHT, DEPTH, r0 + k, HEIGHT)  # one row of the frame
+        if cpu.lib.orx_primary_dirs(ctypes.byref(cam), ctypes.byref(fr), row.ctypes.data) != 0:
+            return None
+        dirs[k] = row[0, c0:c0 + n_crop]
+    orig = np.tile(np.float32(list(cam.origin)), (n_crop * n_crop, 1))
+    ctx.trace_rays(orig, dirs.reshape(-1, 3), DEPTH)
+    st = ctx.stats()
+    secs = st.kernel_ms * 1e-3
+    samples = WIDTH * HEIGHT * 4
+    return {
+        "value": round(st.rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": host_cores(), "kind": "port",
+        "sample": "the pixel-centre rays of the %dx%d centre crop of the %dx%d frame (%d rays of depth %d) through the oracle's "
+                  "Scene::traceRay restatement, OpenMP over rays: %d sceneIntersect calls in %.2f s; the frame has 4 samples per "
+                  "pixel with sub-pixel offsets -- ms_per_frame is this time x %d / %d, an extrapolation"
+                  % (n_crop, n_crop, WIDTH, HEIGHT, n_crop * n_crop, DEPTH, st.rays, secs, samples, n_crop * n_crop),
+        "ms_per_frame": round(secs * 1e3 * samples / (n_crop * n_crop), 1), "extrapolated": True,
     }
 
 
@@ -231,6 +279,14 @@ def live_counters(workload, frames):
     return out
 
 
+def scene_resident_bytes(stress, textures):
+    """Bytes of scene data a frame can read: textures, triangles (48 B), cell keys (16 B), tree nodes (64 B)."""
+    tex = int(textures["water"].size + textures["sky"].size)
+    tris = 4968 * 4 ** 4 if stress else 4968
+    spheres = 10000 if stress else 4
+    return tex + tris * (48 + 16 + 64) + spheres * (16 + 4 + 64)
+
+
 def free_port():
     import socket
     with socket.socket() as sock:
@@ -245,6 +301,88 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd))
+
+
+def group_bench(args, workload_text, metric_text):
+    """--backend group: the frame through rtx_group_* (include/rtx.h) -- one process, one context and render stream per
+    rank, the ranks' rows sent into the root over RCCL and de-interleaved there, the frame left in the root's memory,
+    two buffer sets so that one frame's exchange runs under the next frame's render.  Prints one JSON line."""
+    import numpy as np
+    from raytracing_amd.rtx import ASSETS_DIR, OPT_STATS, Group, hip_backend
+    hip = hip_backend()
+    import torch
+    visible = torch.cuda.device_count()
+    n = args.gpus
+    devices = list(range(n)) if visible >= n else [0] * n
+    textures = {"water": hip.decode_jpeg(os.path.join(ASSETS_DIR, "water.jpg")), "sky": hip.decode_jpeg(os.path.join(ASSETS_DIR, "envmap.jpg"))}
+    stress = args.workload.startswith("stress")
+
+    def load(ctx):
+        if stress:
+            from raytracing_amd import scenes
+            scenes.load_stress_scene(ctx, hip, textures["water"], textures["sky"])
+        else:
+            ctx.load_default_scene(textures["water"], textures["sky"], mask=MASK)
+
+    g = Group(hip, devices)
+    for ctx in g.contexts:
+        load(ctx)
+    g.commit()
+    cam = hip.default_camera()
+    for _ in range(args.warmup):
+        g.render_device(cam, WIDTH, HEIGHT, DEPTH)
+    g.wait()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.render_device(cam, WIDTH, HEIGHT, DEPTH)
+    g.wait()
+    ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+    # one frame at a time: its latency, every rank's kernel time, and what is left for the exchange
+    lat, kernels = [], None
+    for _ in range(10):
+        t1 = time.perf_counter()
+        g.render_device(cam, WIDTH, HEIGHT, DEPTH)
+        g.wait()
+        lat.append((time.perf_counter() - t1) * 1e3)
+        kernels = [c.stats().kernel_ms for c in g.contexts]
+    latency = float(np.median(lat))
+    # into a host buffer, as `rt -gpus N` does (page-locked)
+    locked = hip.host_array((HEIGHT, WIDTH, 3))
+    for _ in range(2):
+        g.render(cam, WIDTH, HEIGHT, DEPTH, out=locked)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        g.render(cam, WIDTH, HEIGHT, DEPTH, out=locked)
+    host_ms = (time.perf_counter() - t1) / 5 * 1e3
+    g.close()
+    # rays per frame (the same whatever the partition): statistics pass on one context
+    sctx = hip.create(0)
+    load(sctx)
+    sctx.set_option(OPT_STATS, 1)
+    sctx.commit()
+    _, st = sctx.render(cam, WIDTH, HEIGHT, DEPTH, want_stats=True)
+    sctx.close()
+    out = {
+        "metric": "Mrays/s (primary+secondary) & ms/frame, " + metric_text,
+        "value": round((st.primary_rays + st.secondary_rays) / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Mrays/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "backend": "group",
+        "data": "the reference's own scene constants and assets (bunny.obj, water.jpg, envmap.jpg)",
+        "config": {"workload": workload_text, "width": WIDTH, "height": HEIGHT, "depth": DEPTH,
+                   "parallelism": "rtx_group_*: one process, %d ranks on device(s) %s, rows interleaved, RCCL send / recv into rank 0%s"
+                                  % (n, sorted(set(devices)), "" if visible >= n else " (fewer GPUs than ranks: the ranks share GPU 0 and render in place)"),
+                   "rays_per_frame": st.rays, "primary": st.primary_rays, "secondary": st.secondary_rays, "shadow": st.shadow_rays,
+                   "mrays_all": round(st.rays / (ms_per_step * 1e-3) / 1e6, 2)},
+        "group": {"ms_per_step_pipelined": round(ms_per_step, 4), "frame_latency_ms": round(latency, 4),
+                  "rank_kernel_ms": [round(k, 4) for k in kernels],
+                  "exchange_and_launch_ms": round(latency - max(kernels), 4),
+                  "host_buffer_ms": round(host_ms, 4),
+                  "what": "ms_per_step_pipelined: K frames enqueued back to back with rtx_group_render_device, one wait at the end; "
+                          "frame_latency_ms: enqueue + rtx_group_wait of one frame (median of 10); rank_kernel_ms: HIP events around each "
+                          "rank's render in that frame; exchange_and_launch_ms: the latency minus the slowest rank; host_buffer_ms: "
+                          "rtx_group_render into page-locked host memory"},
+    }
+    print(json.dumps(out), flush=True)
 
 
 def moved(cam, k):
@@ -264,9 +402,13 @@ def main():
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic stays null)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region, the ray counts and the roofline")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
+    ap.add_argument("--backend", choices=("ranks", "group"), default="ranks",
+                    help="ranks: one process per GPU, torch.distributed gather (the launcher's contract); group: rtx_group_* in one process")
     args = ap.parse_args()
     global WIDTH, HEIGHT, DEPTH, MASK
     WIDTH, HEIGHT, DEPTH, MASK, workload_text, metric_text = WORKLOADS[args.workload]
+    if args.backend == "group":
+        return group_bench(args, workload_text, metric_text)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)
     counter_frames = 2 if args.workload == "stress" else 6
@@ -439,8 +581,12 @@ def main():
                          "lane_slot_frac": round(lane_insts / (N_SIMD * 16 * CLOCK_HZ * secs), 4),
                          "mean_active_lanes": round(lane_insts / wave_insts, 1),
                          "source": "live counter passes (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU) / live kernel time"}
-        # algorithmic bytes: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel
+        # what the walks ask the memory system for: BVH nodes 64 B, triangles 48 B, texels 3 B, framebuffer 3 B/pixel -- requests
+        # that the caches serve, not traffic
         alg_bytes = st.bvh_node_tests * 64 + st.triangle_tests * 48 + (st.sky_lookups + st.plane_tests) * 3 + rows * WIDTH * 3
+        # what a frame must move at the least: the framebuffer out, and in at most once everything it can read
+        scene_bytes = scene_resident_bytes(stress, textures)
+        compulsory = rows * WIDTH * 3 + scene_bytes
         roofline = {
             "bound": "valu", "kernel": "k_wf_trace + k_wf_shadow + k_wf_shade<.., true> (level-by-level pipeline, all launches of a frame)" if stress else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
@@ -448,10 +594,17 @@ def main():
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
                     "the reference bit for bit, so 1 flop/lane/clk = 39.3 TFLOP/s is the most such code can reach",
             "valu_issue": issue, "counters": hw,
-            "hbm": {"algorithmic_bytes_per_launch": int(alg_bytes), "achieved_gbs": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 1),
-                    "peak_gbs": PEAK_HBM_GBS, "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                    "note": "bytes the walks ask for (64 B per node pair, 48 B per triangle, 3 B per texel and pixel); the caches serve "
-                            "most of them, `traffic` is what the counters saw between L2 and memory"},
+            "frac_of_unfused_cap": round(achieved / 39.3, 5),
+            "hbm": {"measured_bytes_per_launch": traffic,
+                    "measured_gbs": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "peak_gbs": PEAK_HBM_GBS, "frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if traffic else None,
+                    "compulsory_bytes_per_launch": int(compulsory),
+                    "compulsory_frac_of_measured": round(compulsory / traffic, 4) if traffic else None,
+                    "l1_request_bytes_per_launch": int(alg_bytes),
+                    "note": "frac = HBM-side bytes the counters saw (`traffic`) / kernel time / 8 TB/s. compulsory = the framebuffer written "
+                            "once + every byte of the resident scene (trees, triangles, textures) read once: an upper bound on what a frame "
+                            "has to move. l1_request_bytes = what the walks ask the caches for (64 B per node visit, 48 B per triangle "
+                            "test, 3 B per texel and pixel): served by L1 / L2, not a traffic figure"},
         }
 
         # ---- the tolerance build of the same sources (librtx_hip_fast.so: contracted multiply-adds, hardware-rate
@@ -509,12 +662,24 @@ def main():
             for _ in range(10):
                 ctx.render(cam, WIDTH, HEIGHT, DEPTH, rank, world)
             host_ms = (time.perf_counter() - t1) / 10 * 1e3
+            # ... and into page-locked memory (rtx_host_alloc), where the copy runs at the speed of the link
+            locked = hip.host_array((rows, WIDTH, 3))
+            for _ in range(3):
+                ctx.render(cam, WIDTH, HEIGHT, DEPTH, rank, world, out=locked)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                ctx.render(cam, WIDTH, HEIGHT, DEPTH, rank, world, out=locked)
+            locked_ms = (time.perf_counter() - t1) / 10 * 1e3
+            del locked
             extra = {"first_frame": {"ms": round(float(np.median(firsts)), 4), "min_ms": round(min(firsts), 4), "max_ms": round(max(firsts), 4),
                                      "what": "device time of the first frame on a fresh context (5 contexts): tile classes from projected "
                                              "boxes + list build + k_render"},
                      "static_order_ms": round(static_ms, 4),
                      "moving_camera_ms": round(moving_ms, 4),
-                     "host_buffer": {"ms": round(host_ms, 4), "what": "wall clock of rtx_render (frame copied to pageable host memory), repeated view"}}
+                     "host_buffer": {"ms": round(locked_ms, 4), "pageable_ms": round(host_ms, 4),
+                                     "what": "wall clock of rtx_render, repeated view: render + copy of the frame into page-locked host memory "
+                                             "(rtx_host_alloc, or the caller's own buffer under RTX_OPT_PIN_OUTPUT) + wait; pageable_ms: "
+                                             "the same into ordinary memory (the runtime's staged copy)"}}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -542,7 +707,9 @@ def main():
         out.update(extra)
         if frame_8k is not None:
             out["frame_8k"] = frame_8k
-        if world == 1 and not args.no_cpu_baseline and (WIDTH, HEIGHT) == (3840, 2160) and not stress:
+        if world == 1 and not args.no_cpu_baseline and stress:
+            out["cpu_baseline"] = cpu_baseline_stress(textures)
+        elif world == 1 and not args.no_cpu_baseline:
             gpu_frame = renderer.render(cam)[0]
             renderer.finish()
             torch.cuda.synchronize()

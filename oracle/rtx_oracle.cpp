@@ -924,12 +924,28 @@ int rtx_trace_rays(rtx_ctx *c, const float *orig, const float *dir, int n, int d
     if (!c || n < 0 || (n > 0 && (!orig || !dir || !rgb_out))) return fail(RTX_E_INVALID, "rtx_trace_rays: bad arguments");
     if (!c->committed) return fail(RTX_E_STATE, "trace before rtx_commit");
     if (depth < 0 || depth > RTX_MAX_DEPTH) return fail(RTX_E_LIMIT, "depth outside [0, RTX_MAX_DEPTH]");
-#pragma omp parallel for schedule(dynamic, 256)
-    for (int i = 0; i < n; ++i) {
-        V3 col = traceRay(*c, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
-                          v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, depth, nullptr);
-        rgb_out[3 * i] = col.x, rgb_out[3 * i + 1] = col.y, rgb_out[3 * i + 2] = col.z;
+    // (ray counts and the time of the loop are kept like rtx_render's: bench.py times a sample of rays this way)
+    Stats total;
+    auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel
+    {
+        Stats local;
+        Stats *st = c->count ? &local : nullptr;
+#pragma omp for schedule(dynamic, 16)
+        for (int i = 0; i < n; ++i) {
+            V3 col = traceRay(*c, v3(orig[3 * i], orig[3 * i + 1], orig[3 * i + 2]),
+                              v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), depth, depth, st);
+            rgb_out[3 * i] = col.x, rgb_out[3 * i + 1] = col.y, rgb_out[3 * i + 2] = col.z;
+        }
+#pragma omp critical
+        {
+            total.primary += local.primary, total.secondary += local.secondary, total.shadow += local.shadow;
+            total.sky += local.sky, total.box_hits += local.box_hits, total.cell_tests += local.cell_tests;
+            total.tri_tests += local.tri_tests;
+        }
     }
+    c->stats = total;
+    c->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RTX_OK;
 }
 
