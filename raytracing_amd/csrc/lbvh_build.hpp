@@ -265,6 +265,7 @@ struct LbvhResult {
 // Morton codes' common prefixes (Karras), agglomerative clustering along the Morton order (ploc_build.hpp), or
 // the top-down binned surface-area heuristic (sah_gpu_build.hpp; bounded to `depth_limit` levels).
 enum class GpuTree { kNone, kMorton, kCluster, kSah };
+constexpr int kTreeGaveUp = 1 << 30;  // LbvhResult.max_depth of a GPU build that gave up: the caller builds the tree on the host
 inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, GpuTree tree, int depth_limit, hipStream_t stream, LbvhResult *out) {
     const bool cluster = tree == GpuTree::kCluster;
     hipError_t err = hipSuccess;
@@ -320,7 +321,11 @@ inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, GpuT
         RTX_HIP_TRY(hipGetLastError());
         out->max_depth = 1;
     } else if (tree == GpuTree::kSah) {
-        RTX_HIP_TRY(sahGpuBuild(d_verts, d_idx, nt, pad, depth_limit, stream, nodes, &out->max_depth));
+        // (a build that gives up -- inconsistent counts from boxes that are not numbers -- is reported as a tree of
+        // unbounded depth: rtx_commit then builds on the host, as it does for a tree too deep for the stack)
+        const hipError_t be = sahGpuBuild(d_verts, d_idx, nt, pad, depth_limit, stream, nodes, &out->max_depth);
+        if (be == hipErrorUnknown || be == hipErrorNotSupported) out->max_depth = kTreeGaveUp, (void)hipGetLastError();
+        else RTX_HIP_TRY(be);
     } else {
         hipLaunchKernelGGL(k_lbvh_morton, dim3(gridT), dim3(B), 0, stream, centroid, cbounds, nt, keys);
         RTX_HIP_TRY(hipGetLastError());
@@ -328,7 +333,9 @@ inline hipError_t lbvhBuild(const float *d_verts, const int *d_idx, int nt, GpuT
         RTX_HIP_TRY(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
         RTX_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys, keys_sorted, nt, 0, 62, stream));
         if (cluster) {
-            RTX_HIP_TRY(plocBuild<Aabb>(keys_sorted, tri_box, nt, pad, stream, nodes, &out->max_depth));
+            const hipError_t be = plocBuild<Aabb>(keys_sorted, tri_box, nt, pad, stream, nodes, &out->max_depth);
+            if (be == hipErrorUnknown || be == hipErrorNotSupported) out->max_depth = kTreeGaveUp, (void)hipGetLastError();
+            else RTX_HIP_TRY(be);
             goto built;
         }
         hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(gridT), dim3(B), 0, stream, keys_sorted, nt, left, right, parent_inner, parent_leaf);

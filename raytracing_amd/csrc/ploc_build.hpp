@@ -117,6 +117,7 @@ __global__ void k_ploc_depth(int n_leaves, const int *__restrict__ parent, int r
 
 // Builds the tree over the n >= 2 triangles whose sorted Morton keys (triangle index in the low word) are `keys`.
 // `nodes` has room for n - 1 entries.  Synchronises the stream (the cluster count comes back once per round).
+// hipErrorNotSupported: the clusters would not merge (see below); nothing usable is in `nodes` then.
 template <typename Box>
 inline hipError_t plocBuild(const unsigned long long *keys, const Box *tri_box, int n, float pad, hipStream_t stream, BvhNode *nodes,
                             int *max_depth_out) {
@@ -149,7 +150,14 @@ inline hipError_t plocBuild(const unsigned long long *keys, const Box *tri_box, 
     PLOC_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, merged, keep, cluster[1], counters + 1, n, stream));
     PLOC_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     hipLaunchKernelGGL(k_ploc_leaves<Box>, dim3((n + B - 1) / B), dim3(B), 0, stream, keys, n, tri_box, pad, box, cluster[0]);
-    while (m > 1) {
+    // Every round costs a synchronisation and a pass over the clusters; a healthy mesh loses a third or more of its
+    // clusters per round.  Many equal union areas (coincident triangles) or boxes that are not numbers make a round
+    // merge next to nothing: such a build is given up (hipErrorNotSupported) and the caller builds the tree another way.
+    for (int round = 0; m > 1; ++round) {
+        if (round >= 96) {
+            err = hipErrorNotSupported;
+            goto done;
+        }
         const dim3 grid((m + B - 1) / B);
         hipLaunchKernelGGL(k_ploc_nearest<Box>, grid, dim3(B), 0, stream, cluster[cur], m, box, nearest, kPlocRadius);
         hipLaunchKernelGGL(k_ploc_merge<Box>, grid, dim3(B), 0, stream, cluster[cur], m, nearest, n, box, left, right, parent, counters, merged, keep);
@@ -157,8 +165,8 @@ inline hipError_t plocBuild(const unsigned long long *keys, const Box *tri_box, 
         PLOC_TRY(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, merged, keep, cluster[cur ^ 1], counters + 1, m, stream));
         PLOC_TRY(hipMemcpyAsync(host, counters, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
         PLOC_TRY(hipStreamSynchronize(stream));
-        if (host[1] >= m || host[1] < 1) {  // every round merges at least the globally closest pair
-            err = hipErrorUnknown;
+        if (host[1] >= m || host[1] < 1 || (long long)(m - host[1]) * 64 < m) {  // (a round merges at least the globally closest pair)
+            err = hipErrorNotSupported;
             goto done;
         }
         m = host[1], cur ^= 1;

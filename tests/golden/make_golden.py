@@ -80,7 +80,9 @@ def tie_pixels(img, mask, sky, W, H, depth):
     and that order follows from heap addresses (the survey's own 7680x4320 digest, made with the same
     sources in another process, differs from this harness's).  The oracle walks a cell's triangles in
     insertion order instead.  Returns [[row, col, b, g, r], ...] with the reference's bytes for the
-    pixels where the two differ; there must be only a handful."""
+    pixels where the two differ; there must be only a handful.  That each of them really is such a tie is
+    checked with the reference's own functions by
+    tests/test_oracle_vs_reference.py::test_address_dependent_pixels_are_exact_distance_ties."""
     from raytracing_amd.rtx import ASSETS_DIR, Backend
     b = Backend(oracle.ORACLE_LIB_PATH)
     ctx = b.create()

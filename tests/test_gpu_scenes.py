@@ -159,6 +159,34 @@ def test_degenerate_mesh_and_duplicate_centroids(hip, oracle_backend, textures, 
     assert abs(out[0, 3] + 20.0) < 1e-5  # the nearest layer
 
 
+@pytest.mark.parametrize("builder", [0, 3])
+def test_coincident_triangles_do_not_stall_the_gpu_builders(hip, oracle_backend, textures, builder):
+    """60 000 copies of one triangle: every union of two clusters has the same area, so the clustering builder merges one
+    pair per round -- it gives up after a bounded number of rounds and the commit builds the tree on the host instead of
+    taking minutes or failing.  Hits equal the oracle's."""
+    import time
+    n = 60_000
+    base = np.array([[-1, -1, -20], [1, -1, -20], [0, 1, -20]], np.float32)
+    verts = np.ascontiguousarray(np.tile(base, (n, 1)))
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    o = np.array([[0, 0, 0], [0.2, -0.3, 0], [5, 5, 0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -1], [0, 0, -1]], np.float32)
+    out = []
+    for b in (hip, oracle_backend):
+        ctx = b.create()
+        ctx.set_materials(b.default_materials())
+        ctx.set_mesh(verts, idx, 3)
+        ctx.set_envmap(textures["map.jpg"])
+        ctx.set_option(OPT_MESH_GRID, 0)
+        ctx.set_option(OPT_BVH_BUILDER, builder)
+        t0 = time.time()
+        ctx.commit()
+        assert time.time() - t0 < 20.0
+        out.append(ctx.intersect_rays(o, d))
+    assert out[0][:, 0].tolist() == [1.0, 1.0, 0.0]
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 def test_clustered_large_mesh_with_an_outlier_builds(hip, oracle_backend, textures):
     """300 000 small triangles inside one Morton cell plus one triangle far away: the Morton-order tree gets
     deeper than the traversal stack; the commit must then fall back to the depth-bounded surface-area builder

@@ -143,3 +143,68 @@ def test_host_layer_against_reference(ref, oracle_backend, tmp_path):
     assert key(tri) == key(mine)
     assert np.array_equal(bbox[:3], v.min(axis=0) - np.float32(1e-4))
     assert np.array_equal(bbox[3:], v.max(axis=0) + np.float32(1e-4))
+
+
+def test_address_dependent_pixels_are_exact_distance_ties(ref, oracle_backend, textures, golden_frames):
+    """The 7680x4320 golden frame lists four pixels as depending on heap addresses (tests patch them before hashing).
+    Evidence, pixel by pixel, with the reference's own functions: somewhere in the pixel's call tree a closest-hit ray
+    hits two (or more) mesh triangles at bit for bit the same distance and that distance is the scene's closest hit --
+    the reference keeps whichever its unordered_set<const Triangle *> iterates first (src/SceneObjects.cpp:363-366).
+    The normal the reference returns for that ray and the normal the oracle returns are both flat normals of tied
+    triangles, and a pixel next to each has no such node."""
+    g8 = golden_frames["G8"]
+    W, H, D = g8["width"], g8["height"], g8["depth"]
+    pixels = g8["address_dependent_pixels"]
+    assert 1 <= len(pixels) <= 8
+    h = ref.ref_scene_create(oracle.REF_RUN_DIR.encode(), g8["mask"], os.path.join(oracle.REF_RESOURCES, g8["envmap"]).encode(),
+                             os.path.join(oracle.REF_RESOURCES, "water.jpg").encode())
+    assert h
+    ref.ref_tie_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    ctx = make_default_context(oracle_backend, textures, mask=g8["mask"], sky=g8["envmap"])
+    lib = oracle_backend.lib
+    lib.orx_primary_dirs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    from raytracing_amd.rtx import Frame
+    cam = oracle_backend.default_camera()
+    eye = np.float32(list(cam.origin))
+    row_dirs = np.zeros((1, W, 3), np.float32)
+
+    def tie_nodes(row, col):
+        fr = Frame(W, H, D, row, H)  # that one row
+        assert lib.orx_primary_dirs(C.byref(cam), C.byref(fr), row_dirs.ctypes.data) == 0
+        d = np.ascontiguousarray(row_dirs[0, col])
+        out = np.zeros((16, 26), np.float32)
+        n = ref.ref_tie_nodes(h, eye.ctypes.data, d.ctypes.data, D, out.ctypes.data, 16)
+        return out[:min(n, 16)]
+
+    def flat_normal(v):  # glm::triangleNormal: normalize(cross(v0 - v1, v0 - v2))
+        n = np.cross(v[0] - v[1], v[0] - v[2]).astype(np.float64)
+        return n / np.linalg.norm(n)
+
+    for row, col, *_ in pixels:
+        nodes = tie_nodes(row, col)
+        assert len(nodes) >= 1, "pixel (%d, %d): no exact tie in its call tree" % (row, col)
+        explained = False
+        for nd in nodes:
+            o, d = np.ascontiguousarray(nd[2:5]), np.ascontiguousarray(nd[5:8])
+            tris = [nd[8:17].reshape(3, 3), nd[17:26].reshape(3, 3)]
+            # the two triangles are hit at the same distance, bit for bit, by the reference's own test
+            dist = []
+            for t in tris:
+                o5 = np.zeros(5, np.float32)
+                ref.ref_triangle(np.ascontiguousarray(t).ctypes.data, 1, o.ctypes.data, d.ctypes.data, o5.ctypes.data)
+                assert o5[0] == 1.0
+                dist.append(o5[1:2].copy())
+            assert dist[0].view(np.uint32)[0] == dist[1].view(np.uint32)[0]
+            # what the reference and the oracle return for this ray: the flat normal of one of the tied triangles each
+            want = np.zeros((1, 16), np.float32)
+            ref.ref_scene_intersect(h, 1, o.ctypes.data, d.ctypes.data, want.ctypes.data)
+            got = ctx.intersect_rays(o.reshape(1, 3), d.reshape(1, 3))
+            assert want[0, 0] == 1.0 and got[0, 0] == 1.0
+            assert np.array_equal(want[0, 1:4].view(np.uint32), got[0, 1:4].view(np.uint32))  # same hit point
+            normals = [flat_normal(t) for t in tris]
+            for n in (want[0, 4:7], got[0, 4:7]):
+                assert nd[1] > 2 or min(np.abs(n - m).max() for m in normals) < 1e-5
+            if not np.array_equal(want[0, 4:7], got[0, 4:7]):
+                explained = True  # the two implementations kept different triangles of the tie: the pixel differs
+        assert explained, "pixel (%d, %d): ties found, but the reference and the oracle keep the same triangle" % (row, col)
+        assert len(tie_nodes(row, col + 2)) == 0 or len(tie_nodes(row + 2, col)) == 0  # (not every pixel around it has one)
