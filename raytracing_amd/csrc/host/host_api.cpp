@@ -126,6 +126,10 @@ int rt_load_model(const char *path, float scale, const float *off, float **verts
     long vertNum = 0, faceNum = 0;
     if (!nextLong(vertNum) || !nextLong(faceNum) || vertNum < 0 || faceNum < 0 || vertNum > (1 << 28) || faceNum > (1 << 28))
         return hostFail("rt_load_model: bad header");
+    // a record is at least "v 0 0 0": a header that promises more records than the file can hold is not believed
+    // (the arrays below are sized by it)
+    if ((unsigned long long)(vertNum + faceNum) * 7 > (unsigned long long)text.size() + 7)
+        return hostFail("rt_load_model: the header counts more records than the file holds");
     float *v = (float *)malloc(sizeof(float) * 3 * (size_t)(vertNum ? vertNum : 1));
     int *f = (int *)malloc(sizeof(int) * 3 * (size_t)(faceNum ? faceNum : 1));
     if (!v || !f) {

@@ -174,23 +174,32 @@ constexpr int fx(double x) { return (int)(x * 4096 + 0.5); }
 // One 8-point inverse DCT pass (the even/odd split of the "islow" algorithm, constants scaled by
 // 4096).  Returns the even part in e[0..3] and the odd part in o[0..3]; output k is e[k] + o[3-k]
 // for k < 4 and e[7-k] - o[k-4] for k >= 4, before the pass-specific rounding and shift.
-inline void idct8(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int e[4], int o[4]) {
+// (The arithmetic is 32-bit two's complement that wraps, written out in unsigned: a damaged file can hold coefficients
+// that overflow it, and the values of an intact one are the same either way.)
+inline void idct8(int i0, int i1, int i2, int i3, int i4, int i5, int i6, int i7, int e[4], int o[4]) {
+    using U = uint32_t;
+    const U s0 = (U)i0, s1 = (U)i1, s2 = (U)i2, s3 = (U)i3, s4 = (U)i4, s5 = (U)i5, s6 = (U)i6, s7 = (U)i7;
+    constexpr auto k = [](double x) { return (U)fx(x); };
     // even part: rotate (s2, s6), butterfly (s0, s4)
-    const int z = (s2 + s6) * fx(0.5411961f);
-    const int r2 = z + s6 * fx(-1.847759065f);
-    const int r3 = z + s2 * fx(0.765366865f);
-    const int a0 = (s0 + s4) * 4096, a1 = (s0 - s4) * 4096;
-    e[0] = a0 + r3, e[3] = a0 - r3, e[1] = a1 + r2, e[2] = a1 - r2;
+    const U z = (s2 + s6) * k(0.5411961f);
+    const U r2 = z + s6 * k(-1.847759065f);
+    const U r3 = z + s2 * k(0.765366865f);
+    const U a0 = (s0 + s4) * 4096u, a1 = (s0 - s4) * 4096u;
+    e[0] = (int)(a0 + r3), e[3] = (int)(a0 - r3), e[1] = (int)(a1 + r2), e[2] = (int)(a1 - r2);
     // odd part on (s7, s5, s3, s1)
-    const int q3 = s7 + s3, q4 = s5 + s1, q1 = s7 + s1, q2 = s5 + s3;
-    const int z5 = (q3 + q4) * fx(1.175875602f);
-    const int m1 = z5 + q1 * fx(-0.899976223f), m2 = z5 + q2 * fx(-2.562915447f);
-    const int m3 = q3 * fx(-1.961570560f), m4 = q4 * fx(-0.390180644f);
-    o[3] = s1 * fx(1.501321110f) + (m1 + m4);
-    o[2] = s3 * fx(3.072711026f) + (m2 + m3);
-    o[1] = s5 * fx(2.053119869f) + (m2 + m4);
-    o[0] = s7 * fx(0.298631336f) + (m1 + m3);
+    const U q3 = s7 + s3, q4 = s5 + s1, q1 = s7 + s1, q2 = s5 + s3;
+    const U z5 = (q3 + q4) * k(1.175875602f);
+    const U m1 = z5 + q1 * k(-0.899976223f), m2 = z5 + q2 * k(-2.562915447f);
+    const U m3 = q3 * k(-1.961570560f), m4 = q4 * k(-0.390180644f);
+    o[3] = (int)(s1 * k(1.501321110f) + (m1 + m4));
+    o[2] = (int)(s3 * k(3.072711026f) + (m2 + m3));
+    o[1] = (int)(s5 * k(2.053119869f) + (m2 + m4));
+    o[0] = (int)(s7 * k(0.298631336f) + (m1 + m3));
 }
+
+// a + b and a - b of 32-bit two's complement values that wrap
+inline int wrapAdd(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+inline int wrapSub(int a, int b) { return (int)((uint32_t)a - (uint32_t)b); }
 
 void idctBlock(uint8_t *out, int stride, const int16_t d[64]) {
     int val[64];
@@ -200,16 +209,16 @@ void idctBlock(uint8_t *out, int stride, const int16_t d[64]) {
         int *v = val + i;
         if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
             // a column with only a DC term is that term scaled to the pass's 2 extra bits
-            const int dc = c[0] * 4;
+            const int dc = c[0] * 4;  // (16 bits times 4: no overflow)
             for (int k = 0; k < 8; ++k) v[8 * k] = dc;
             continue;
         }
         idct8(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56], e, o);
         // drop the 12 constant bits but keep 2 bits of extra precision: round at bit 9
         for (int k = 0; k < 4; ++k) {
-            const int x = e[k] + 512;
-            v[8 * k] = (x + o[3 - k]) >> 10;
-            v[8 * (7 - k)] = (x - o[3 - k]) >> 10;
+            const int x = wrapAdd(e[k], 512);
+            v[8 * k] = wrapAdd(x, o[3 - k]) >> 10;
+            v[8 * (7 - k)] = wrapSub(x, o[3 - k]) >> 10;
         }
     }
     for (int i = 0; i < 8; ++i) {  // rows
@@ -219,9 +228,9 @@ void idctBlock(uint8_t *out, int stride, const int16_t d[64]) {
         // 12 constant bits + 2 kept bits + 3 bits from the two sqrt(8) scalings = 17: round there,
         // and move -128..127 to 0..255 in the same addition
         for (int k = 0; k < 4; ++k) {
-            const int x = e[k] + 65536 + (128 << 17);
-            row[k] = clampByte((x + o[3 - k]) >> 17);
-            row[7 - k] = clampByte((x - o[3 - k]) >> 17);
+            const int x = wrapAdd(e[k], 65536 + (128 << 17));
+            row[k] = clampByte(wrapAdd(x, o[3 - k]) >> 17);
+            row[7 - k] = clampByte(wrapSub(x, o[3 - k]) >> 17);
         }
     }
 }
@@ -422,8 +431,8 @@ struct Decoder {
         memset(data, 0, 64 * sizeof(int16_t));
         if (t > 16) bad("bad huffman code");
         const int diff = t ? br.receiveExtend(t) : 0;
-        c.dc_pred += diff;
-        data[0] = (int16_t)(c.dc_pred * dq[0]);
+        c.dc_pred = wrapAdd(c.dc_pred, diff);
+        data[0] = (int16_t)((uint32_t)c.dc_pred * dq[0]);
         int k = 1;
         do {
             const int rs = br.decode(ac);
@@ -448,8 +457,8 @@ struct Decoder {
             const int t = br.decode(dc);
             if (t > 16) bad("bad huffman code");
             const int diff = t ? br.receiveExtend(t) : 0;
-            c.dc_pred += diff;
-            data[0] = (int16_t)(c.dc_pred << succ_low);
+            c.dc_pred = wrapAdd(c.dc_pred, diff);
+            data[0] = (int16_t)((uint32_t)c.dc_pred << succ_low);
         } else if (br.getBit()) {
             data[0] += (int16_t)(1 << succ_low);
         }
@@ -480,7 +489,7 @@ struct Decoder {
                 } else {
                     k += r;
                     const int zig = kDezigzag[k++];
-                    data[zig] = (int16_t)(br.receiveExtend(s) << shift);
+                    data[zig] = (int16_t)((uint32_t)br.receiveExtend(s) << shift);
                 }
             } while (k <= spec_end);
         } else {  // refinement pass (G.1.2.3)
