@@ -211,16 +211,17 @@ def test_deterministic(hip, textures):
     assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
-@pytest.mark.parametrize("quad", [0, 1, 2])
-@pytest.mark.parametrize("size", [(331, 207), (640, 360)])
-def test_every_frame_writes_every_pixel(hip, oracle_backend, textures, quad, size):
+@pytest.mark.parametrize("quad, probe", [(0, 0), (1, 0), (2, 0), (1, 1)])
+@pytest.mark.parametrize("size", [(331, 207), (640, 360), (803, 601)])
+def test_every_frame_writes_every_pixel(hip, oracle_backend, textures, quad, probe, size):
     """The frame buffer is overwritten with a pattern before every render: whatever list a frame is
-    scheduled by (static classes, cost bins with quad-mode quarters, the kept list, a nearby view's
-    costs), every tile must be on it -- a tile left out would show the pattern, not an old frame."""
+    scheduled by (static classes from projected boxes or -- frames of 4096 tiles and more with
+    RTX_OPT_TILE_PROBE -- from one probe ray per tile, cost bins with quad-mode quarters, the kept list, a
+    nearby view's costs), every tile must be on it -- a tile left out would show the pattern, not an old frame."""
     import torch
-    from raytracing_amd.rtx import Frame
+    from raytracing_amd.rtx import OPT_TILE_PROBE, Frame
     w, h = size
-    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad)])
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad), (OPT_TILE_PROBE, probe)])
     octx = make_default_context(oracle_backend, textures, sky="map.jpg")
     cam, ocam = hip.default_camera(), oracle_backend.default_camera()
     x0 = cam.origin[0]
