@@ -1,6 +1,8 @@
 """HIP path on scenes other than the default one: the LBVH against a brute-force closest hit,
 empty / degenerate inputs, API errors, sharded frames, the de-interleave kernel, full-size
 properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,29 @@ def test_all_tree_builders_give_the_same_hits(hip, textures, n_tris):
     assert (out[0][:, 0] > 0).sum() > (0 if n_tris < 300 else 100)
     for other in out[1:]:
         assert np.array_equal(out[0].view(np.uint32), other.view(np.uint32))
+
+
+def test_large_nodes_built_by_many_workgroups_give_the_host_builder_tree(hip, textures):
+    """The GPU surface-area builder builds nodes of more than 4096 references with many workgroups (bounds, bins,
+    partition in chunks) and smaller ones with one wave each.  Both follow the host builder's algorithm step by step:
+    on a mesh without coincident centroids the three give the same tree (up to the order of two leaves under one node:
+    the host's partition is not a stable one), so a frame costs exactly the same number of node tests whether the GPU
+    (79 488 triangles: 6 levels of large nodes) or the host built it."""
+    from raytracing_amd.rtx import ASSETS_DIR, OPT_STATS
+    v, f = hip.load_model(os.path.join(ASSETS_DIR, "bunny.obj"), 45.0, (4.0, -7.0 + 1.4, -23.0))
+    verts, idx = _subdivide(v, f, 2)
+    counts, frames = [], []
+    for builder in (0, 2):
+        ctx = make_default_context(hip, textures, mask=31 - 8, sky="map.jpg", options=[(OPT_STATS, 1), (OPT_BVH_BUILDER, builder)], commit=False)
+        ctx.set_mesh(verts, idx, 3)
+        ctx.commit()
+        frame, st = ctx.render(hip.default_camera(), 640, 360, 4, want_stats=True)
+        counts.append((st.bvh_node_tests, st.triangle_tests, st.rays))
+        frames.append(frame)
+    assert counts[0][0] > 100000
+    assert counts[0][0] == counts[1][0] and counts[0][2] == counts[1][2]
+    assert abs(counts[0][1] - counts[1][1]) < 0.01 * counts[0][1]
+    assert np.array_equal(frames[0], frames[1])
 
 
 def _subdivide(verts, idx, levels):
