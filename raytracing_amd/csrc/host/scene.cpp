@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 
 #include "../../../include/rt_host.h"
@@ -165,6 +166,10 @@ int Scene::upload(rtx_ctx *ctx, unsigned mask, const std::string &bunny_path, co
 int Scene::run(const Settings &settings) const {
     using clock = std::chrono::steady_clock;
     const auto t_start = clock::now();
+    const bool stages = getenv("RT_TIMING") != nullptr;  // where the run's time goes, to stderr
+    auto stage = [&](const char *what) {
+        if (stages) std::cerr << "[rt] " << what << " done at " << std::chrono::duration<double>(clock::now() - t_start).count() << " s" << std::endl;
+    };
     // (the reference's frame size is a compile-time constant; here it comes from the command line)
     if (settings.width <= 0 || settings.height <= 0 || (long long)settings.width * settings.height > (1ll << 30) || settings.depth < 0) {
         std::cout << "Error: bad frame size or depth (" << settings.width << " x " << settings.height << ", depth " << settings.depth << ")" << std::endl;
@@ -184,34 +189,50 @@ int Scene::run(const Settings &settings) const {
     std::cout << "Scene number: " << settings.scene << std::endl;
     std::cout << "Threads: " << settings.threads << " (ignored: the pixel loop runs on " << settings.gpus << " GPU(s) from " << settings.device << ")" << std::endl;
     std::cout << "\nRendering image..." << std::endl;
-    if (rt_decode_jpeg(sky_path.c_str(), &sky, &sw, &sh, &sn) != 0 || sn != 3) {
-        // the reference prints this and then crashes in the first sky lookup (src/SceneObjects.cpp:424-427, 444)
-        std::cout << "Error: can not load the environment map" << std::endl;
-        rt_free(water), rt_free(sky);
-        return -1;
-    }
+    // The panorama (tens of megapixels) is decoded on a thread of its own while this one brings up the GPUs: the two
+    // take about as long as each other, and the reference's run is dominated by exactly this loading (src/Scene.cpp:260).
+    auto sky_decoded = std::async(std::launch::async, [&]() { return rt_decode_jpeg(sky_path.c_str(), &sky, &sw, &sh, &sn); });
     // one context per GPU, the same scene on each; one GPU is a group of one
     std::vector<int> ids;
     for (int k = 0; k < (settings.gpus > 1 ? settings.gpus : 1); ++k) ids.push_back(settings.device + k);
     rtx_group *group = nullptr;
     int rc = rtx_group_create(&group, ids.data(), (int)ids.size());
+    stage("rtx_group_create");
+    if (sky_decoded.get() != 0 || sn != 3) {
+        // the reference prints this and then crashes in the first sky lookup (src/SceneObjects.cpp:424-427, 444)
+        std::cout << "Error: can not load the environment map" << std::endl;
+        rt_free(water), rt_free(sky);
+        rtx_group_destroy(group);
+        return -1;
+    }
     for (int r = 0; rc == 0 && r < (int)ids.size(); ++r)
         rc = upload(rtx_group_ctx(group, r), RT_MASK_ALL, settings.resources + "/bunny.obj", water, ww, wh, sky, sw, sh);
+    stage("panorama decoded, scene handed over");
     rt_free(water), rt_free(sky);
     if (rc == 0) rc = rtx_group_commit(group);
-    std::vector<unsigned char> image;
+    stage("rtx_group_commit");
+    // (page-locked: the frame leaves the GPU at the speed of the link)
+    unsigned char *image = nullptr;
+    if (rc == 0 && !(image = static_cast<unsigned char *>(rtx_host_alloc((size_t)settings.width * settings.height * 3)))) {
+        std::cerr << "rtx error: no host memory for the frame" << std::endl;
+        rtx_group_destroy(group);
+        return -1;
+    }
     if (rc == 0) {
-        image.resize((size_t)settings.width * settings.height * 3);
         rtx_camera cam;
         defaultCamera(&cam);
         const auto t0 = clock::now();
-        rc = rtx_group_render(group, &cam, settings.width, settings.height, settings.depth, image.data(), nullptr);
+        rc = rtx_group_render(group, &cam, settings.width, settings.height, settings.depth, image, nullptr);
         const auto t1 = clock::now();
         if (rc == 0) std::cout << "Done. Render time: " << std::chrono::duration<double>(t1 - t0).count() << std::endl;
     }
     if (rc != 0) std::cerr << "rtx error: " << (rtx_group_last_error()[0] ? rtx_group_last_error() : rtx_last_error()) << std::endl;
-    if (rc == 0) rc = rt_save_bmp(image.data(), settings.width, settings.height, settings.out.c_str());
+    stage("frame");
+    if (rc == 0) rc = rt_save_bmp(image, settings.width, settings.height, settings.out.c_str());
+    stage("file written");
+    rtx_host_free(image);
     rtx_group_destroy(group);
+    stage("rtx_group_destroy");
     std::cout << "Total time (including loading textures and models): "
               << std::chrono::duration<double>(clock::now() - t_start).count() << std::endl;
     return rc == 0 ? 0 : -1;

@@ -560,20 +560,23 @@ struct FrameSpill {
     FrameHead heads[kMaxDepth];
     FrameRay rays[kMaxDepth];
 };
+// (LDS through a pointer that says so: through a plain pointer the compiler merges the LDS read and the scratch read of
+// frameHead into one flat load of a selected address, which waits for both memory pipes)
+using LdsFloat = __attribute__((address_space(3))) float;
 struct FrameStack {
-    float *lds;
+    LdsFloat *lds;
     int lds_slots, lds_stride;
     FrameHead *heads;
     FrameRay *rays;
 };
 
 RTX_DEV FrameStack frameStack(FrameSpill &spill, float *lds = nullptr, int lds_slots = 0, int lds_stride = 0) {
-    return FrameStack{lds, lds_slots, lds_stride, spill.heads, spill.rays};
+    return FrameStack{(LdsFloat *)lds, lds_slots, lds_stride, spill.heads, spill.rays};
 }
 
 RTX_DEV FrameHead frameHead(const FrameStack &fs, int j) {
     if (j < fs.lds_slots) {
-        const float *p = fs.lds + 6 * j * fs.lds_stride;
+        const LdsFloat *p = fs.lds + 6 * j * fs.lds_stride;
         FrameHead f;
         f.acc = v3(p[0], p[fs.lds_stride], p[2 * fs.lds_stride]);
         f.a2 = p[3 * fs.lds_stride], f.a3 = p[4 * fs.lds_stride];
@@ -585,7 +588,7 @@ RTX_DEV FrameHead frameHead(const FrameStack &fs, int j) {
 
 RTX_DEV void frameSetHead(FrameStack &fs, int j, const FrameHead &f) {
     if (j < fs.lds_slots) {
-        float *p = fs.lds + 6 * j * fs.lds_stride;
+        LdsFloat *p = fs.lds + 6 * j * fs.lds_stride;
         p[0] = f.acc.x, p[fs.lds_stride] = f.acc.y, p[2 * fs.lds_stride] = f.acc.z;
         p[3 * fs.lds_stride] = f.a2, p[4 * fs.lds_stride] = f.a3;
         p[5 * fs.lds_stride] = __int_as_float(f.state);
@@ -597,7 +600,7 @@ RTX_DEV void frameSetHead(FrameStack &fs, int j, const FrameHead &f) {
 // after the reflect child: only the partial sum and the state have changed
 RTX_DEV void frameSetSum(FrameStack &fs, int j, const FrameHead &f) {
     if (j < fs.lds_slots) {
-        float *p = fs.lds + 6 * j * fs.lds_stride;
+        LdsFloat *p = fs.lds + 6 * j * fs.lds_stride;
         p[0] = f.acc.x, p[fs.lds_stride] = f.acc.y, p[2 * fs.lds_stride] = f.acc.z;
         p[5 * fs.lds_stride] = __int_as_float(f.state);
     } else {
