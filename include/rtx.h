@@ -142,6 +142,17 @@ enum rtx_option {
                                  and the mirror / glass spheres.  Measured: a first frame of the mesh over the water
                                  14 % shorter, of the full default scene 10 % longer (the probe launch costs 0.1 ms),
                                  hence off by default.  Scheduling only: pixels do not change                     */
+    RTX_OPT_QUAD_KERNEL = 14, /* 0/1/2 (default 1): the quad-mode tiles of RTX_OPT_QUAD are traced by a launch of their
+                                 own beside the frame's main launch (on a stream of the context's, forked off the
+                                 render's stream and joined to it again before the call returns), in which the idle
+                                 fourth lane of a pixel casts the node's first child ray during the shadow trip: a node
+                                 then takes one trip instead of two.  0 = never (inside the main launch, without that),
+                                 2 = whenever the tile list has quad-mode tiles, 1 = for frames small enough to be
+                                 bounded by their longest chains (up to 16 tiles per resident wave: 1920x1080 on an
+                                 MI355X, or an eighth of 3840x2160 -- 9 to 12 % shorter there, 8 % longer for a whole
+                                 3840x2160 frame).  Renders that are being captured into a graph, and
+                                 rtx_render_device_noalloc, always take the first form.  Pixels and ray counts do not
+                                 change                                                                            */
     RTX_OPT_PIN_OUTPUT = 12,  /* 0/1 (default 0): rtx_render / rtx_group_render may page-lock the caller's output buffer
                                  (hipHostRegister) and keep it so while the same buffer keeps being passed: the frame
                                  then leaves the GPU at the speed of the link instead of through the runtime's pageable

@@ -97,6 +97,8 @@ constexpr unsigned kQuadFlag = 0x80000000u, kTileMask = 0x0fffffffu;
 // hold the frame up: they are entered as four quarters, all others once.  Never tiles shorter than
 // min_ticks, never more than `cap` tiles.
 constexpr float kQuadShare = 0.8f;
+constexpr unsigned kQuadCostScale = 3;
+constexpr int kSideLaunchTiles = 16;   // tiles per resident wave up to which the quad-mode tiles get a launch of their own  // the quad-mode launch: time of a tile's first quarter -> stand-in for the whole tile's time
 
 // The tile list of a frame from the costs of the previous one, without a sort: the tiles are dealt into
 // bins by cost on a logarithmic scale of eight steps per octave, most expensive first.  The bins above
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(const unsigned *__res
 // the average cost
 __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ block_hist, const unsigned long long *__restrict__ block_sum,
                                                         unsigned n, unsigned wave_slots, float quad_share, unsigned min_ticks, unsigned cap,
-                                                        unsigned cheap_cost, unsigned *__restrict__ n_out, unsigned *__restrict__ head) {
+                                                        unsigned cheap_cost, unsigned *__restrict__ n_out, unsigned *__restrict__ head,
+                                                        unsigned *quads_for_host) {
     __shared__ unsigned s_total[kCostBins], s_start[kCostBins];
     const unsigned b = threadIdx.x;
     unsigned at = 0;
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(kCostBins) void k_bin_scan(unsigned *__restrict__ b
         if (cheap_from < heavy) cheap_from = heavy;
         n_out[0] = n + 3u * heavy;
         n_out[1] = 3u * heavy + cheap_from;
+        n_out[2] = 4u * heavy;  // the quarters come first
+        if (quads_for_host) *quads_for_host = heavy;  // (page-locked host memory: sizes the grid of the next quad-mode launches)
         head[0] = heavy, head[1] = heavy_bins;
     }
     __syncthreads();
@@ -272,7 +277,7 @@ struct PixelJob {
 
 // Advances the lane's path, one ray per trip, until it is complete; the pixel's B,G,R bytes
 // (include/bitmap_image.hpp:207-209) go to `bgr` (the wave's tile buffer in LDS).
-template <bool STATS, bool WIDE>
+template <bool STATS, bool WIDE, bool LOOK = false>
 __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &q, const DevCamera &cam, const DevFrame &fr, PixelJob job,
                                            PathState &st, FrameStack &frames, bool active, const int quad_j, unsigned char *bgr, int *stack,
                                            LaneCounters<STATS> &lc) {
@@ -284,10 +289,11 @@ __device__ __forceinline__ void tracePaths(const DevScene &s, const SmallScene &
         float md = 0.0f;
         if (pathCasts(st, quad_j)) {
             pathCountRay<STATS>(st, quad_j, lc);
-            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, st.light >= 0, st.t_exit, h, md, stack, kBlock, lc);
+            const bool shadow = st.light >= 0 && !(LOOK && pathRayIsAhead(st, quad_j));
+            hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, shadow, st.t_exit, h, md, stack, kBlock, lc);
         }
         V3 c;
-        if (pathConsume<STATS, WIDE>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
+        if (pathConsume<STATS, WIDE, LOOK>(s, q, st, frames, hit, h, md, quad_j, c, lc)) {
             if constexpr (WIDE) {
                 if (fr.spp > 1) {
                     // RTX_OPT_SPP = 4: (((c0 + c1) + c2) + c3) * 0.25 over the rotated grid of include/rtx.h
@@ -385,12 +391,18 @@ template <typename G, typename T> __device__ __forceinline__ G *inDeviceMemory(T
 // k_render's per-lane LDS (sized by the launch): the traversal stack, then the frame heads; dword k of lane t at [k * kBlock + t]
 extern __shared__ int s_lane_lds[];
 
-template <bool STATS, bool WIDE>
+// LOOK = the launch for the quad-mode tiles, beside the frame's main launch (on a stream of its own): its waves take
+// the quarters at the head of the list (the first list_hdr[2] entries, through queue heads of their own) and trace them
+// with the look-ahead ray of pathConsume, then join the main launch's queues.  The look-ahead keeps a second hit record
+// alive through the cast; in a loop that shares its registers with the one-lane-per-pixel loop the latter pays for
+// that, so the main launch (LOOK = false, `split`) is compiled without it and starts behind the quarters.  Together
+// the two launches have as many workgroups as fit the GPU at once, so neither waits for the other whichever starts first.
+template <bool STATS, bool WIDE, bool LOOK>
 __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevScene s, DevCamera cam_arg, DevFrame fr_arg, unsigned tiles_x_arg, unsigned n_tiles,
                                                    const unsigned *order_arg, const unsigned *__restrict__ n_entries_dev,
                                                    unsigned batch_from_arg, unsigned *heads_arg, unsigned *heads_next,
                                                    unsigned *tile_cost_arg, unsigned char *out_arg,
-                                                   Counters *counters) {
+                                                   Counters *counters, unsigned split, unsigned *quad_heads, unsigned *quad_heads_next) {
     __shared__ SmallScene q;
     __shared__ unsigned char s_tile[kBlock / 64][192];  // the B,G,R bytes of a wave's tile: 8 rows of 24 bytes
     __shared__ float s_samples[WIDE ? kBlock / 64 : 1][WIDE ? 4 * 64 * 3 : 1];  // tracePathPool: colours per sample and pixel
@@ -425,17 +437,23 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
     const unsigned lane = threadIdx.x & 63u;
     // the queue heads come in two sets: this launch counts in one and clears the other for the next
     // launch of the context (launches of a context follow one another), which saves a fill per frame
-    if (blockIdx.x == 0 && threadIdx.x < kQueues) heads_next[threadIdx.x * kHeadStride] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kQueues) (LOOK ? quad_heads_next : heads_next)[threadIdx.x * kHeadStride] = 0u;
     // rows of whole dwords: a finished tile goes out as 48 dword stores instead of 192 byte stores
     const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
     // the list has one entry per tile, or four for a tile that is traced in quad mode (see kQuadFlag)
-    const unsigned n_entries = n_entries_dev ? n_entries_dev[0] : n_tiles;
+    // `split`: the quarters at the head of the list are the quad-mode launch's, the main queues start behind them
+    const unsigned skip = split && n_entries_dev ? n_entries_dev[2] : 0u;
+    const unsigned n_entries = (n_entries_dev ? n_entries_dev[0] : n_tiles) - skip;
     // entries from here on are cheap tiles (below the average cost of the previous frame, or outside every
     // projected bounding box on the first frame of a view)
-    const unsigned batch_from = n_entries_dev ? n_entries_dev[1] : batch_from_arg;
+    const unsigned batch_from_all = n_entries_dev ? n_entries_dev[1] : batch_from_arg;
+    const unsigned batch_from = batch_from_all > skip ? batch_from_all - skip : 0u;
     const unsigned my_len = lane < n_entries ? (n_entries - lane + kQueues - 1u) / kQueues : 0u;  // entries of queue `lane`
-    unsigned qi = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;  // wave-uniform: current queue
+    const unsigned my_quarters = LOOK && lane < skip ? (skip - lane + kQueues - 1u) / kQueues : 0u;  // ... of the quarters' queue `lane`
+    bool quarters_left = LOOK;  // wave-uniform: the quarters' queues have not been seen empty yet
+    const unsigned first_queue = (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kQueues;
+    unsigned qi = first_queue;  // wave-uniform: current queue
     LaneCounters<STATS> lc;
     PathState st;
     FrameSpill spill;  // the heads of the first frames in LDS, what is indexed dynamically beyond them in scratch memory
@@ -456,7 +474,33 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
     for (;;) {
         // ---- take a tile ----
         unsigned tile = 0xffffffffu;
-        if (batch_k < batch_n) tile = __builtin_amdgcn_readlane(batch, batch_k++);
+        if constexpr (LOOK) {
+            // the quarters first, one at a time
+            while (quarters_left) {
+                const unsigned len = __builtin_amdgcn_readlane(my_quarters, qi);
+                unsigned i = len;
+                if (lane == 0 && len)
+                    i = __hip_atomic_fetch_add(inDeviceMemory<GlobalU32>(quad_heads + qi * kHeadStride), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                i = __builtin_amdgcn_readfirstlane(i);
+                if (i < len) {
+                    unsigned e = 0;
+                    if (lane == 0) e = *inDeviceMemory<const GlobalU32>(order + qi + i * kQueues);
+                    tile = __builtin_amdgcn_readfirstlane(e);
+                    break;
+                }
+                const unsigned head = __hip_atomic_load(inDeviceMemory<GlobalU32>(quad_heads + lane * kHeadStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long live = __ballot(head < my_quarters);
+                live &= ~(1ull << qi);
+                if (!live) {
+                    quarters_left = false, qi = first_queue;  // on with the main launch's queues
+                    break;
+                }
+                const unsigned long long after = qi == 63u ? 0ull : live & (~0ull << (qi + 1u));
+                qi = (unsigned)__builtin_ctzll(after ? after : live);
+            }
+        }
+        if (tile != 0xffffffffu) {
+        } else if (batch_k < batch_n) tile = __builtin_amdgcn_readlane(batch, batch_k++);
         else for (;;) {
             const unsigned len = __builtin_amdgcn_readlane(my_len, qi);
             const unsigned want = cheap_zone ? batch_max : 1u;
@@ -468,7 +512,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
                 const unsigned n = want < len - i ? want : len - i;
                 const unsigned e = qi + (i + lane) * kQueues;
                 batch = 0xffffffffu;
-                if (lane < n) batch = order ? *inDeviceMemory<const GlobalU32>(order + e) : e;
+                if (lane < n) batch = order ? *inDeviceMemory<const GlobalU32>(order + skip + e) : e;
                 batch_n = n, batch_k = 1u;
                 cheap_zone = qi + (i + n) * kQueues >= batch_from;
                 tile = __builtin_amdgcn_readlane(batch, 0);
@@ -511,12 +555,13 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
         const long long t_tile = wall_clock64();
         // two copies of the loop, one per mode: in the common one quad_j is the constant -1 and the quad
         // logic folds away
-        if (quad) tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
+        if (quad) tracePaths<STATS, WIDE, LOOK>(s, q, cam, fr, job, st, frames, active, quad_j, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         else if (WIDE && fr.spp > 1) tracePathPool<STATS>(s, q, cam, fr, x0, y0, st, frames, s_samples[WIDE ? threadIdx.x >> 6 : 0], s_tile[threadIdx.x >> 6], stack, lc);
         else tracePaths<STATS, WIDE>(s, q, cam, fr, job, st, frames, active, -1, &s_tile[threadIdx.x >> 6][3 * pix], stack, lc);
         // what the tile cost (100 MHz ticks): the next frame of the same view starts the expensive ones first
         // (a quarter in quad mode runs about half as long as the whole tile would: the first quarter stands for it)
-        if (lane == 0 && (!quad || sub == 0u)) *inDeviceMemory<GlobalU32>(tile_cost + tile) = (unsigned)(wall_clock64() - t_tile) << (quad ? 1 : 0);
+        // (with the look-ahead about a third as long)
+        if (lane == 0 && (!quad || sub == 0u)) *inDeviceMemory<GlobalU32>(tile_cost + tile) = (unsigned)(wall_clock64() - t_tile) * (quad ? (LOOK ? kQuadCostScale : 2u) : 1u);
         // ---- write the tile: all 64 lanes are here.  LDS operations of a wave complete in order; the
         // fences keep the compiler from moving the reads above the byte writes. ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -731,7 +776,7 @@ struct SchedMem {
     unsigned *heads = nullptr;     // work-queue heads of k_render, two sets: a launch counts in one and clears the other
     unsigned *cost = nullptr;      // per tile: what it cost in the last frame (100 MHz ticks), or its class's stand-in cost
     unsigned *entries = nullptr;   // the tile list built from it: `quarters` x cap entries (the longest tiles as four quarters)
-    unsigned *list_hdr = nullptr;  // {entries in the list, first cheap entry}
+    unsigned *list_hdr = nullptr;  // {entries in the list, first cheap entry, quarters at the head of the list}
     unsigned *bins = nullptr;      // k_bin_*: per-workgroup histograms, then two words of header
     unsigned long long *bin_sums = nullptr;
     size_t cap = 0;                // tiles that cost and entries are sized for
@@ -751,11 +796,12 @@ struct ViewKey {
 };
 // What a SchedMem holds at the moment.
 struct SchedState {
-    bool heads_flip = false;
+    bool heads_flip = false, quad_flip = false;  // which set of queue heads the next main / quad-mode launch counts in
     bool have_cost = false;  // `cost` holds the measured costs of a frame: of cost_view
     ViewKey cost_view;
     ViewKey by_cost_key;     // `entries` was built from measured costs for this view
     ViewKey static_key;      // `entries` was built from the tile classes for this view
+    bool list_quads = false; // the list in `entries` may start with quarters (quad-mode tiles)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -859,6 +905,11 @@ struct rtx_ctx {
     int feedback = 1;                       // RTX_OPT_SCHEDULE_FEEDBACK
     int quad_mode = 1;                      // RTX_OPT_QUAD
     int tile_probe = 0;                     // RTX_OPT_TILE_PROBE
+    int quad_kernel = 1;                    // RTX_OPT_QUAD_KERNEL
+    hipStream_t quad_stream = nullptr;      // the quad-mode launch runs beside the main one: forked off the render's stream and joined again
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int resident_quad[4] = {0, 0, 0, 0};    // most workgroups of the quad-mode launch k_render<STATS, WIDE, true> that are resident at once
+    unsigned *host_quads = nullptr;         // page-locked: quad-mode tiles of the list k_bin_scan built last
     SchedMem sched;                         // the context's own scheduling memory (grown on demand)
     SchedState sched_state;
     int pipeline = 2;                       // RTX_OPT_PIPELINE
@@ -1074,8 +1125,9 @@ DevScene sceneForLaunch(const rtx_ctx *c, float origin_reach) {
 }
 
 using RenderKernel = void (*)(DevScene, DevCamera, DevFrame, unsigned, unsigned, const unsigned *, const unsigned *, unsigned, unsigned *,
-                              unsigned *, unsigned *, unsigned char *, Counters *);
-const RenderKernel kRenderKernels[4] = {k_render<false, false>, k_render<true, false>, k_render<false, true>, k_render<true, true>};
+                              unsigned *, unsigned *, unsigned char *, Counters *, unsigned, unsigned *, unsigned *);
+const RenderKernel kRenderKernels[4] = {k_render<false, false, false>, k_render<true, false, false>, k_render<false, true, false>, k_render<true, true, false>};
+const RenderKernel kQuadKernels[4] = {k_render<false, false, true>, k_render<true, false, true>, k_render<false, true, true>, k_render<true, true, true>};
 
 // bytes of k_render's per-lane LDS
 constexpr size_t renderLds(int stack_entries, int frame_slots) { return (size_t)(stack_entries + 6 * frame_slots) * kBlock * sizeof(int); }
@@ -1104,6 +1156,10 @@ int residentBlocks(rtx_ctx *c) {
         }
         (void)hipGetLastError();
         c->lds_frame_slots[variant] = slots;
+        // the quad-mode launch with the same per-lane LDS
+        int quad_per_cu = 0;
+        HIP_OR_FAIL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&quad_per_cu, kQuadKernels[variant], kBlock, renderLds(c->stack_entries, slots)));
+        c->resident_quad[variant] = (quad_per_cu > 0 ? quad_per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1);
     }
     return RTX_OK;
 }
@@ -1179,16 +1235,47 @@ int launchRender(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsigned
         hipLaunchKernelGGL(k_bin_count, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, m.bin_sums);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(kCostBins), 0, stream, m.bins, m.bin_sums, (unsigned)n_tiles,
                            (unsigned)resident * (kBlock / 64u), quad_share, quad_min, cap,
-                           by_cost ? 0u : (how == kFromProbes ? kProbeCheapCost : kClassCheapCost), m.list_hdr, d_head);
+                           by_cost ? 0u : (how == kFromProbes ? kProbeCheapCost : kClassCheapCost), m.list_hdr, d_head,
+                           m.quarters ? c->host_quads : nullptr);
         hipLaunchKernelGGL(k_bin_scatter, dim3(kBinBlocks), dim3(kBinThreads), 0, stream, m.cost, (unsigned)n_tiles, per, m.bins, d_head,
                            m.entries);
         HIP_OR_FAIL(hipGetLastError());
         ss.by_cost_key.valid = ss.static_key.valid = false;
         (how == kFromCosts ? ss.by_cost_key : ss.static_key).set(cam, f);
+        ss.list_quads = cap > 0;
     }
-    hipLaunchKernelGGL(kRenderKernels[variant], dim3(blocks), dim3(kBlock), renderLds(fr.stack_entries, fr.lds_frames), stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
-                       order, list_hdr, batch_from, heads, heads_next, m.cost, d_out, c->d_counters);
+    // The quad-mode tiles go to a launch of their own (k_render<.., LOOK = true>) on the context's side stream, between a
+    // fork off `stream` and a join back into it, so that the two launches run side by side.  Not while a graph is being
+    // captured (one stream, one node) and not from the static scheduling memory (no quarters there): the main launch
+    // then traces them itself.  The side launch gets one workgroup per quad-mode tile of the list, as the host last saw
+    // their number (k_bin_scan writes it into page-locked memory: exact for a kept list once the frame that built it
+    // is through, the previous list's otherwise -- with too few, each takes more quarters; none seen yet, no side
+    // launch), and the main launch that many fewer: together they fit the GPU at once.
+    // It pays where the longest chains bound the frame, not the throughput (RTX_OPT_QUAD_KERNEL = 1: frames of at most
+    // kSideLaunchTiles tiles per wave that is resident; measured on the default scene: 800x600 -9 %, 1920x1080 -10 %,
+    // an eighth / a quarter of a 3840x2160 frame -12 %, half of one +11 %, all of one +8 %).
+    const unsigned quads_seen = c->host_quads ? *(volatile unsigned *)c->host_quads : 0u;
+    const bool chain_bound = n_tiles <= (long long)kSideLaunchTiles * resident * (kBlock / 64);
+    const bool split = order && ss.list_quads && m.quarters && (c->quad_kernel == 2 || (c->quad_kernel == 1 && chain_bound)) && c->quad_stream && timed &&
+                       quads_seen > 0 && blocks > 1;
+    unsigned main_blocks = blocks;
+    if (split) {
+        const unsigned quad_blocks = std::min<unsigned>(std::min<unsigned>(quads_seen, blocks / 2u), (unsigned)c->resident_quad[variant]);
+        main_blocks = blocks - quad_blocks;
+        HIP_OR_FAIL(hipEventRecord(c->ev_fork, stream));
+        HIP_OR_FAIL(hipStreamWaitEvent(c->quad_stream, c->ev_fork, 0));
+        unsigned *const qheads = m.heads + kHeadWords + (ss.quad_flip ? kQueues * kHeadStride : 0u);
+        unsigned *const qheads_next = m.heads + kHeadWords + (ss.quad_flip ? 0u : kQueues * kHeadStride);
+        hipLaunchKernelGGL(kQuadKernels[variant], dim3(quad_blocks), dim3(kBlock), renderLds(fr.stack_entries, fr.lds_frames), c->quad_stream, s, devCamera(cam), fr,
+                           (unsigned)tiles_x, (unsigned)n_tiles, order, list_hdr, batch_from, heads, heads_next, m.cost, d_out, c->d_counters, 1u, qheads, qheads_next);
+        HIP_OR_FAIL(hipGetLastError());
+        ss.quad_flip = !ss.quad_flip;  // (the side launch has cleared the other set for its next time, whenever that is)
+        HIP_OR_FAIL(hipEventRecord(c->ev_join, c->quad_stream));
+    }
+    hipLaunchKernelGGL(kRenderKernels[variant], dim3(main_blocks), dim3(kBlock), renderLds(fr.stack_entries, fr.lds_frames), stream, s, devCamera(cam), fr, (unsigned)tiles_x, (unsigned)n_tiles,
+                       order, list_hdr, batch_from, heads, heads_next, m.cost, d_out, c->d_counters, split ? 1u : 0u, (unsigned *)nullptr, (unsigned *)nullptr);
     HIP_OR_FAIL(hipGetLastError());
+    if (split) HIP_OR_FAIL(hipStreamWaitEvent(stream, c->ev_join, 0));
     ss.heads_flip = !ss.heads_flip;  // only now: a launch that failed has cleared nothing
     ss.cost_view.set(cam, f), ss.have_cost = true;
     if (timed) HIP_OR_FAIL(hipEventRecord(c->ev1, stream));
@@ -1413,14 +1500,19 @@ int rtx_create(rtx_ctx **out, int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc((void **)&c->d_counters, sizeof(Counters))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->sched.heads, kHeadWords * sizeof(unsigned))) != hipSuccess ||
-        (e = hipMemset(c->sched.heads, 0, kHeadWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->sched.heads, 2 * kHeadWords * sizeof(unsigned))) != hipSuccess ||  // the main launch's and the quad-mode launch's
+        (e = hipMemset(c->sched.heads, 0, 2 * kHeadWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->quad_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->host_quads, sizeof(unsigned), hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc((void **)&c->sched.bins, kBinWords * sizeof(unsigned))) != hipSuccess ||
-        (e = hipMalloc((void **)&c->sched.list_hdr, 2 * sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc((void **)&c->sched.list_hdr, 4 * sizeof(unsigned))) != hipSuccess ||
         (e = hipMalloc((void **)&c->sched.bin_sums, kBinBlocks * sizeof(unsigned long long))) != hipSuccess) {
         rtx_destroy(c);
         return failHip(e, "rtx_create");
     }
+    *c->host_quads = 0u;
     if (int rc = scratchOnDevice(device_id)) {
         rtx_destroy(c);
         return rc;
@@ -1433,6 +1525,10 @@ void rtx_destroy(rtx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->quad_stream) (void)hipStreamSynchronize(c->quad_stream), (void)hipStreamDestroy(c->quad_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->host_quads) (void)hipHostFree(c->host_quads);
     for (void *p : c->owned) (void)hipFree(p);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->sched.heads);
@@ -1482,6 +1578,10 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (c->committed) return fail(RTX_E_STATE, "RTX_OPT_BVH_BUILDER must be set before rtx_commit");
             if (value > 3) return fail(RTX_E_INVALID, "RTX_OPT_BVH_BUILDER: 0 surface-area heuristic on the GPU, 1 Morton order on the GPU, 2 surface-area heuristic on the host, 3 clustering on the GPU");
             c->bvh_builder = (int)value;
+            break;
+        case RTX_OPT_QUAD_KERNEL:
+            if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD_KERNEL: 0 never, 1 automatic, 2 whenever there are quad-mode tiles");
+            c->quad_kernel = (int)value;
             break;
         case RTX_OPT_TILE_PROBE:
             c->tile_probe = value != 0;

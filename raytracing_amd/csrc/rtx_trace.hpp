@@ -620,11 +620,12 @@ struct PathState {
     Material m;
     float ndl, lightDist, Ld, Ls;
     int cast_mask;  // quad mode: which lights of the current batch of four get a shadow ray
+    bool ahead;     // quad mode with look-ahead: lane 3 casts the first child's closest-hit ray beside the shadow rays
 };
 
 RTX_DEV void pathStart(PathState &st, V3 orig, V3 dir, int depth) {
     st.orig = orig, st.dir = dir, st.depth = depth, st.fullDepth = depth, st.sp = 0;
-    st.light = -1, st.t_exit = -1.0f, st.cast_mask = 0;
+    st.light = -1, st.t_exit = -1.0f, st.cast_mask = 0, st.ahead = false;
 }
 
 // Quad mode.  Four neighbouring lanes (a "quad") can share ONE pixel: all four hold the same path
@@ -633,6 +634,12 @@ RTX_DEV void pathStart(PathState &st, V3 orig, V3 dir, int depth) {
 // of one plus one per light, which halves the longest chains of the frame at the price of three
 // redundant lanes; the kernel uses it for the few tiles that last longest.  quad_j is the lane's
 // place in its quad (0..3), or -1 in the normal one-pixel-per-lane mode.
+//
+// Look-ahead (LOOK: the quad-mode launch of k_render).  With three lights the fourth lane of a quad has nothing to
+// do in the shadow trip.  Where the node's first child ray goes depends on the hit alone, not on the lights
+// (src/Scene.cpp:95-101), so that lane casts the child's closest-hit ray in the same trip; its hit record is handed
+// round the quad afterwards and the child becomes the current node without a trip of its own.  A node then costs one
+// trip instead of two.  The rays cast, their order per pixel and every sum are the same as without it.
 
 // Does the pending ray have to be cast at all?  (A closest-hit ray of depth 0 is answered by the
 // sky; in quad mode a lane casts only its own light of the batch.)
@@ -641,9 +648,16 @@ RTX_DEV bool pathCasts(const PathState &st, int quad_j) {
     return st.depth > 0;
 }
 
+// is this lane's pending ray the look-ahead ray of its quad (a closest-hit ray although st.light >= 0)?
+RTX_DEV bool pathRayIsAhead(const PathState &st, int quad_j) { return st.ahead && quad_j == 3; }
+
 template <bool STATS>
 RTX_DEV void pathCountRay(const PathState &st, int quad_j, LaneCounters<STATS> &lc) {
     if constexpr (STATS) {
+        if (pathRayIsAhead(st, quad_j)) {  // the child's closest-hit ray: it is not cast again when the child's turn comes
+            lc.v[CNT_SECONDARY] += 1u;
+            return;
+        }
         const bool shadow = st.light >= 0;
         const bool first = quad_j <= 0;  // the four lanes of a quad cast the same closest-hit ray: count it once
         lc.v[CNT_SHADOW] += shadow ? 1u : 0u;
@@ -728,11 +742,35 @@ RTX_DEV int quadBroadcast(int v) {
 // Consumes the result of the pending ray (hit, h, md: what castEnd returned; hit = false when the ray
 // was not cast) and sets up the next one.  Returns true when the whole tree is done; `color` is
 // then the value traceRay would have returned.
-template <bool STATS, bool WIDE = false>
-RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, FrameStack &frames, bool hit, const Hit &h, float md,
+// value of lane 3 of the caller's quad, for every field of a hit record
+RTX_DEV float quadFromLane3(float v) { return __int_as_float(quadBroadcast<3>(__float_as_int(v))); }
+RTX_DEV Hit quadHitFromLane3(const Hit &h) {
+    Hit r;
+    r.point = v3(quadFromLane3(h.point.x), quadFromLane3(h.point.y), quadFromLane3(h.point.z));
+    r.N = v3(quadFromLane3(h.N.x), quadFromLane3(h.N.y), quadFromLane3(h.N.z));
+    r.m.refractive = quadFromLane3(h.m.refractive), r.m.a0 = quadFromLane3(h.m.a0), r.m.a1 = quadFromLane3(h.m.a1);
+    r.m.a2 = quadFromLane3(h.m.a2), r.m.a3 = quadFromLane3(h.m.a3);
+    r.m.dr = quadFromLane3(h.m.dr), r.m.dg = quadFromLane3(h.m.dg), r.m.db = quadFromLane3(h.m.db), r.m.spec = quadFromLane3(h.m.spec);
+    r.mat_index = quadBroadcast<3>(h.mat_index);
+    return r;
+}
+
+// the origin of a node's child ray of direction d: the point moved along N to the side the child leaves on.
+// point - N * e is point + N * (-e) bit for bit, which saves choosing between two vectors
+RTX_DEV V3 pathChildOrigin(const DevScene &s, const PathState &st, V3 d) {
+#pragma clang fp contract(off)
+    return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec);
+}
+
+template <bool STATS, bool WIDE = false, bool LOOK = false>
+RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, FrameStack &frames, bool hit, const Hit &h_cast, float md,
                          int quad_j, V3 &color, LaneCounters<STATS> &lc) {
-    const bool shadow = st.light >= 0;
     const bool count = quad_j <= 0;  // statistics: once per pixel
+    Hit h = h_cast;
+    bool ahead_known = false, ahead_hit = false;  // LOOK: the first child's closest-hit result came with this trip
+    Hit ahead_h = h_cast;
+    for (;;) {  // (a second turn only with LOOK: for the child whose result is already here)
+    const bool shadow = st.light >= 0;
     bool returning = false;          // `color` holds the finished value of a node
     if (shadow && quad_j < 0) {
         // ---- after the shadow ray of light st.light ----
@@ -746,6 +784,14 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         // lane of the quad adds all of them up, in the reference's order, so the four states stay equal.
         const int mine = ((st.cast_mask >> quad_j) & 1) && pathShadowed(st, hit, md) ? 1 : 0;
         const int hidden[4] = {quadBroadcast<0>(mine), quadBroadcast<1>(mine), quadBroadcast<2>(mine), quadBroadcast<3>(mine)};
+        if constexpr (LOOK) {
+            if (st.ahead) {  // lane 3 cast the first child's closest-hit ray: everyone takes its result
+                ahead_known = true;
+                ahead_hit = quadBroadcast<3>(hit ? 1 : 0) != 0;
+                ahead_h = quadHitFromLane3(h);
+                st.ahead = false;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int li = st.light + k;
@@ -790,6 +836,21 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                 }
             }
             if (mask) {
+                if constexpr (LOOK) {
+                    // the last batch of lights and lane 3 is free: it casts the closest-hit ray of the node's first child
+                    // (the ray the code below will make the pending one when the lights are done)
+                    if (st.light + 3 >= s.n_lights && st.depth > 1) {
+                        const bool doRefl = !s.prune || st.m.a2 != 0.0f, doRefr = !s.prune || st.m.a3 != 0.0f;
+                        if (doRefl || doRefr) {
+                            st.ahead = true;
+                            mask |= 8;
+                            if (quad_j == 3) {
+                                const V3 d = doRefl ? reflectDir(st.view, st.N) : normalize(refractDir(st.view, st.N, st.m.refractive));
+                                st.orig = pathChildOrigin(s, st, d), st.dir = d, st.t_exit = -1.0f;
+                            }
+                        }
+                    }
+                }
                 st.cast_mask = mask;
                 return false;
             }
@@ -806,12 +867,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         if (!doRefl && !doRefr) {
             color = base;
         } else {
-            // the child's origin: the point moved along N to the side the child leaves on.  point - N * e is
-            // point + N * (-e) bit for bit, which saves choosing between two vectors
-            const auto childOrigin = [&](V3 d) {
-#pragma clang fp contract(off)
-                return st.point + st.N * (__builtin_signbit(dot(d, st.N)) ? -s.fprec : s.fprec);
-            };
+            const auto childOrigin = [&](V3 d) { return pathChildOrigin(s, st, d); };
             V3 reflD = v3(0, 0, 0), refrD = v3(0, 0, 0);
             if (doRefl) reflD = reflectDir(dir, st.N);
             if (doRefr) refrD = normalize(refractDir(dir, st.N, m.refractive));
@@ -847,6 +903,13 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
                 // the pending refract ray is only stored when there is one (most nodes have the reflect child alone)
                 if (f.state & 2) frames.rays[j].orig = refrO, frames.rays[j].dir = refrD;
                 st.depth = depth - 1;
+                if constexpr (LOOK) {
+                    if (ahead_known) {  // the pending ray has been cast already: on with its result
+                        ahead_known = false;
+                        hit = ahead_hit, h = ahead_h;
+                        continue;
+                    }
+                }
                 return false;
             }
         }
@@ -871,6 +934,7 @@ RTX_DEV bool pathConsume(const DevScene &s, const SmallScene &q, PathState &st, 
         --st.sp;
     }
     return true;
+    }
 }
 
 template <bool STATS, bool WIDE = false>

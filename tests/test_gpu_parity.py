@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import PSNR_MIN_DB, WITHIN_ONE_MIN, compare_frames, make_default_context
-from raytracing_amd.rtx import OPT_MESH_GRID, OPT_PRUNE, OPT_QUAD, OPT_SCHEDULE_FEEDBACK, OPT_STATS
+from raytracing_amd.rtx import OPT_MESH_GRID, OPT_PRUNE, OPT_QUAD, OPT_QUAD_KERNEL, OPT_SCHEDULE_FEEDBACK, OPT_STATS
 
 pytestmark = pytest.mark.gpu
 
@@ -162,13 +162,15 @@ def test_ray_counts_match_oracle(hip, oracle_backend, textures):
     assert g.kernel_ms > 0
 
 
-@pytest.mark.parametrize("quad", [0, 1, 2])
-def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_frames, golden_small, quad):
+@pytest.mark.parametrize("quad, own_kernel", [(0, 1), (1, 1), (2, 2), (1, 0), (2, 0)])
+def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_frames, golden_small, quad, own_kernel):
     """The first frame of a view runs in the static tile order, the second lists the tiles by what they
     cost and (RTX_OPT_QUAD) traces the expensive ones -- here: none / some / all -- with four lanes per
-    pixel.  Every frame must be the reference's G1 frame, with the same ray counts."""
+    pixel, in a kernel of their own with the look-ahead child ray (RTX_OPT_QUAD_KERNEL) or inside the main
+    launch.  Every frame must be the reference's G1 frame, with the same ray counts."""
     cfg = golden_frames["G1"]
-    ctx = make_default_context(hip, textures, mask=cfg["mask"], sky=cfg["envmap"], options=[(OPT_STATS, 1), (OPT_QUAD, quad)])
+    ctx = make_default_context(hip, textures, mask=cfg["mask"], sky=cfg["envmap"],
+                               options=[(OPT_STATS, 1), (OPT_QUAD, quad), (OPT_QUAD_KERNEL, own_kernel)])
     counts = []
     for _ in range(4):
         frame, st = ctx.render(hip.default_camera(), cfg["width"], cfg["height"], cfg["depth"], want_stats=True)
@@ -180,13 +182,13 @@ def test_scheduling_never_changes_pixels_or_ray_counts(hip, textures, golden_fra
     assert counts[0] == (st.primary_rays, st.secondary_rays, st.shadow_rays, st.sky_lookups, st.lit_lights)
 
 
-@pytest.mark.parametrize("quad", [1, 2])
-def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures, quad):
+@pytest.mark.parametrize("quad, own_kernel", [(1, 1), (2, 2), (1, 0)])
+def test_moving_camera_keeps_frames_exact(hip, oracle_backend, textures, quad, own_kernel):
     """A camera that stands still, moves a little per frame, stands still, jumps somewhere else and back,
     and a change of frame size in between: frames are scheduled by the static classes (first frame, a
     cut), by the previous frame's costs (a nearby view) or by the kept list (the same view).  None of
     that may show in the pixels."""
-    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad)])
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad), (OPT_QUAD_KERNEL, own_kernel)])
     octx = make_default_context(oracle_backend, textures, sky="map.jpg")
     cam = hip.default_camera()
     ocam = oracle_backend.default_camera()
@@ -211,17 +213,17 @@ def test_deterministic(hip, textures):
     assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
-@pytest.mark.parametrize("quad, probe", [(0, 0), (1, 0), (2, 0), (1, 1)])
+@pytest.mark.parametrize("quad, probe, own_kernel", [(0, 0, 1), (1, 0, 1), (2, 0, 2), (1, 1, 1), (1, 0, 0), (2, 0, 0)])
 @pytest.mark.parametrize("size", [(331, 207), (640, 360), (803, 601)])
-def test_every_frame_writes_every_pixel(hip, oracle_backend, textures, quad, probe, size):
+def test_every_frame_writes_every_pixel(hip, oracle_backend, textures, quad, probe, own_kernel, size):
     """The frame buffer is overwritten with a pattern before every render: whatever list a frame is
     scheduled by (static classes from projected boxes or -- frames of 4096 tiles and more with
-    RTX_OPT_TILE_PROBE -- from one probe ray per tile, cost bins with quad-mode quarters, the kept list, a
-    nearby view's costs), every tile must be on it -- a tile left out would show the pattern, not an old frame."""
+    RTX_OPT_TILE_PROBE -- from one probe ray per tile, cost bins with quad-mode quarters (traced by the main launch or by
+    a kernel of their own beside it), the kept list, a nearby view's costs), every tile must be on it -- a tile left out would show the pattern, not an old frame."""
     import torch
     from raytracing_amd.rtx import OPT_TILE_PROBE, Frame
     w, h = size
-    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad), (OPT_TILE_PROBE, probe)])
+    ctx = make_default_context(hip, textures, sky="map.jpg", options=[(OPT_QUAD, quad), (OPT_TILE_PROBE, probe), (OPT_QUAD_KERNEL, own_kernel)])
     octx = make_default_context(oracle_backend, textures, sky="map.jpg")
     cam, ocam = hip.default_camera(), oracle_backend.default_camera()
     x0 = cam.origin[0]

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 #           kernel                        most scratch bytes per lane, most spilled VGPRs, most VGPRs
-LIMITS = {"k_render<false, false>": (512, 16, 168),  # three waves per SIMD; the frames of the recursion beyond the LDS slots live in scratch
+LIMITS = {"k_render<false, false, false>": (512, 16, 168),  # three waves per SIMD; the frames of the recursion beyond the LDS slots live in scratch
+          "k_render<false, false, true>": (640, 48, 168),   # the quad-mode launch beside it: must fit the same slots (its look-ahead hit record spills)
           "k_wf_trace<false, false>": (64, 12, 128),  # the pipeline's walking kernels: four waves per SIMD ...
           "k_wf_shadow<false, false>": (0, 0, 128),
           "k_wf_trace<false, true>": (192, 48, 96),   # ... and five in the general build (a stress-scene frame takes 4 % less
