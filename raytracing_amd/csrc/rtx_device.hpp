@@ -147,7 +147,11 @@ struct SmallScene {
     float4 islands[kMaxSmallPrims];
     float tris[kMaxSmallPrims * 9];
     float boxes[kMaxSmallPrims * 6];
-    int sphere_mat[kMaxSmallPrims], tri_mat[kMaxSmallPrims], box_mat[kMaxSmallPrims];
+    // material index of whatever a ray can hit, in ONE array: spheres at 0, loose triangles at kMaxSmallPrims, boxes at
+    // 2 kMaxSmallPrims, then the mesh, the water, the islands.  The hit record reads it with a computed slot; read from a
+    // list per kind (and from kernel arguments for the last three) the compiler is free to merge the reads into one
+    // flat load of a selected address, which waits for both memory pipes -- and did, on and off, with unrelated edits.
+    int prim_mat[3 * kMaxSmallPrims + 4];
     // Constants of the scene that every ray looks at (copies of DevScene's): as kernel arguments they would sit in
     // scalar registers for the whole kernel, which has too few of those (the overflow is parked in vector-register
     // lanes and fetched back with a vector instruction per use); from here they cost a broadcast read.
@@ -168,13 +172,14 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
     copy(q.lights, s.lights, staged(s.n_lights, kMaxLights) * 4);
     if (s.n_spheres <= kMaxSmallPrims) {  // larger sets stay in global memory behind their BVH
         copy(q.spheres, s.spheres, s.n_spheres * 4);
-        copy(q.sphere_mat, s.sphere_mat, s.n_spheres);
+        copy(q.prim_mat, s.sphere_mat, s.n_spheres);
     }
     copy(q.islands, s.islands, staged(s.n_islands, kMaxSmallPrims) * 4);
     copy(q.tris, s.tris, staged(s.n_tris, kMaxSmallPrims) * 9);
-    copy(q.tri_mat, s.tri_mat, staged(s.n_tris, kMaxSmallPrims));
+    copy(q.prim_mat + kMaxSmallPrims, s.tri_mat, staged(s.n_tris, kMaxSmallPrims));
     copy(q.boxes, s.boxes, staged(s.n_boxes, kMaxSmallPrims) * 6);
-    copy(q.box_mat, s.box_mat, staged(s.n_boxes, kMaxSmallPrims));
+    copy(q.prim_mat + 2 * kMaxSmallPrims, s.box_mat, staged(s.n_boxes, kMaxSmallPrims));
+    if (t == 0) q.prim_mat[3 * kMaxSmallPrims] = s.mesh_mat, q.prim_mat[3 * kMaxSmallPrims + 1] = s.water_mat, q.prim_mat[3 * kMaxSmallPrims + 2] = s.island_mat;
     copy(&q.math, &kRefMathTables, (int)(sizeof(RefMathTables) / 4));
     copy(q.sphere_bounds, s.sphere_bounds, 6), copy(q.tri_bounds, s.tri_bounds, 6), copy(q.box_bounds, s.box_bounds, 6);
     copy(q.object_bounds, s.object_bounds, 6);
@@ -184,13 +189,67 @@ __device__ __forceinline__ void loadSmallScene(SmallScene &q, const DevScene &s)
 
 // List entry i: from the staging while it reaches, from global memory beyond.  Only the general build of the
 // kernels (WIDE) knows about lists longer than the staging; the host launches it when a scene has one.
-template <bool WIDE> __device__ __forceinline__ float4 lightAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxLights ? q.lights[i] : s.lights[i]; }
-template <bool WIDE> __device__ __forceinline__ Material materialAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxMaterials ? q.materials[i] : s.materials[i]; }
-template <bool WIDE> __device__ __forceinline__ float4 islandAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.islands[i] : s.islands[i]; }
-template <bool WIDE> __device__ __forceinline__ const float *triAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.tris + 9 * i : s.tris + 9 * (size_t)i; }
-template <bool WIDE> __device__ __forceinline__ const float *boxAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.boxes + 6 * i : s.boxes + 6 * (size_t)i; }
-template <bool WIDE> __device__ __forceinline__ int triMatAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.tri_mat[i] : s.tri_mat[i]; }
-template <bool WIDE> __device__ __forceinline__ int boxMatAt(const DevScene &s, const SmallScene &q, int i) { return !WIDE || i < kMaxSmallPrims ? q.box_mat[i] : s.box_mat[i]; }
+// (The staged entry is read through a pointer that says LDS: through plain pointers the compiler merges the LDS read
+// and the global read of such a pair into one flat load of a selected address, slower than either and a wait for both
+// memory pipes.  Only the general build has the pair; in the default build every read below is an LDS read anyway.)
+using LdsFloats = const __attribute__((address_space(3))) float *;
+using LdsInts = const __attribute__((address_space(3))) int *;
+__device__ __forceinline__ LdsFloats inLds(const float *p) { return (LdsFloats)p; }
+__device__ __forceinline__ LdsInts inLds(const int *p) { return (LdsInts)p; }
+__device__ __forceinline__ float4 ldsFloat4(const float4 *p) {
+    const LdsFloats f = inLds(reinterpret_cast<const float *>(p));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+template <bool WIDE> __device__ __forceinline__ float4 lightAt(const DevScene &s, const SmallScene &q, int i) {
+    if (WIDE && i >= kMaxLights) return s.lights[i];
+    return ldsFloat4(q.lights + i);
+}
+template <bool WIDE> __device__ __forceinline__ Material materialAt(const DevScene &s, const SmallScene &q, int i) {
+    if (WIDE && i >= kMaxMaterials) return s.materials[i];
+    const LdsFloats f = inLds(reinterpret_cast<const float *>(q.materials + i));
+    return Material{f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8]};
+}
+template <bool WIDE> __device__ __forceinline__ float4 islandAt(const DevScene &s, const SmallScene &q, int i) {
+    if (WIDE && i >= kMaxSmallPrims) return s.islands[i];
+    return ldsFloat4(q.islands + i);
+}
+// a loose triangle's nine floats, a box's six
+struct Floats9 { float v[9]; __host__ __device__ const float &operator[](int k) const { return v[k]; } };
+struct Floats6 { float v[6]; __host__ __device__ const float &operator[](int k) const { return v[k]; } };
+template <bool WIDE> __device__ __forceinline__ Floats9 triAt(const DevScene &s, const SmallScene &q, int i) {
+    Floats9 r;
+    if (WIDE && i >= kMaxSmallPrims) {
+        const float *g = s.tris + 9 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r.v[k] = g[k];
+    } else {
+        const LdsFloats f = inLds(q.tris + 9 * i);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r.v[k] = f[k];
+    }
+    return r;
+}
+template <bool WIDE> __device__ __forceinline__ Floats6 boxAt(const DevScene &s, const SmallScene &q, int i) {
+    Floats6 r;
+    if (WIDE && i >= kMaxSmallPrims) {
+        const float *g = s.boxes + 6 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r.v[k] = g[k];
+    } else {
+        const LdsFloats f = inLds(q.boxes + 6 * i);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r.v[k] = f[k];
+    }
+    return r;
+}
+// material index of hit kind 1..6 (sphere, loose triangle, box, mesh triangle, water, island), list entry i
+template <bool WIDE> __device__ __forceinline__ int hitMaterialIndex(const DevScene &s, const SmallScene &q, int kind, int i) {
+    if constexpr (WIDE) {
+        if (kind == 1 && s.sphere_bvh) return s.sphere_mat[i];
+        if ((kind == 2 || kind == 3) && i >= kMaxSmallPrims) return (kind == 2 ? s.tri_mat : s.box_mat)[i];
+    }
+    return inLds(q.prim_mat)[kind <= 3 ? (kind - 1) * kMaxSmallPrims + i : 3 * kMaxSmallPrims + kind - 4];
+}
 
 // Statistics slots, in the order of rtx_stats' 64-bit fields (include/rtx.h).
 enum CounterSlot {

@@ -419,8 +419,11 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
         unsigned char *out;
     };
     __shared__ TileArgs ta;
+    // `split`: the quarters at the head of the list are the quad-mode launch's, the main queues start behind them
+    const unsigned skip = split && n_entries_dev ? n_entries_dev[2] : 0u;
+    const unsigned *const order_behind = order_arg ? order_arg + skip : nullptr;
     if (threadIdx.x == 0) {
-        ta.cam = cam_arg, ta.fr = fr_arg, ta.tiles_x = tiles_x_arg, ta.order = order_arg, ta.heads = heads_arg, ta.tile_cost = tile_cost_arg;
+        ta.cam = cam_arg, ta.fr = fr_arg, ta.tiles_x = tiles_x_arg, ta.order = order_behind, ta.heads = heads_arg, ta.tile_cost = tile_cost_arg;
         ta.out = out_arg;
     }
     loadSmallScene(q, s);
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
     const DevCamera &cam = *(WIDE ? &cam_arg : &ta.cam);
     const DevFrame &fr = *(WIDE ? &fr_arg : &ta.fr);
     const unsigned &tiles_x = *(WIDE ? &tiles_x_arg : &ta.tiles_x);
-    const unsigned *const &order = *(WIDE ? &order_arg : &ta.order);
+    const unsigned *const &order = *(WIDE ? &order_behind : &ta.order);
     unsigned *const &heads = *(WIDE ? &heads_arg : &ta.heads);
     unsigned *const &tile_cost = *(WIDE ? &tile_cost_arg : &ta.tile_cost);
     unsigned char *const &out = *(WIDE ? &out_arg : &ta.out);
@@ -442,8 +445,6 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
     const bool dword_rows = (fr.width & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     static_assert(kQueues == 64, "one queue head per lane in the scan below");
     // the list has one entry per tile, or four for a tile that is traced in quad mode (see kQuadFlag)
-    // `split`: the quarters at the head of the list are the quad-mode launch's, the main queues start behind them
-    const unsigned skip = split && n_entries_dev ? n_entries_dev[2] : 0u;
     const unsigned n_entries = (n_entries_dev ? n_entries_dev[0] : n_tiles) - skip;
     // entries from here on are cheap tiles (below the average cost of the previous frame, or outside every
     // projected bounding box on the first frame of a view)
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
                 i = __builtin_amdgcn_readfirstlane(i);
                 if (i < len) {
                     unsigned e = 0;
-                    if (lane == 0) e = *inDeviceMemory<const GlobalU32>(order + qi + i * kQueues);
+                    if (lane == 0) e = *inDeviceMemory<const GlobalU32>(order_arg + qi + i * kQueues);
                     tile = __builtin_amdgcn_readfirstlane(e);
                     break;
                 }
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(kBlock, STATS || WIDE ? 2 : 3) void k_render(DevSce
                 const unsigned n = want < len - i ? want : len - i;
                 const unsigned e = qi + (i + lane) * kQueues;
                 batch = 0xffffffffu;
-                if (lane < n) batch = order ? *inDeviceMemory<const GlobalU32>(order + skip + e) : e;
+                if (lane < n) batch = order ? *inDeviceMemory<const GlobalU32>(order + e) : e;
                 batch_n = n, batch_k = 1u;
                 cheap_zone = qi + (i + n) * kQueues >= batch_from;
                 tile = __builtin_amdgcn_readlane(batch, 0);

@@ -442,33 +442,28 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     // ---- resolve the winner: hit point, normal, material ----
     if (kind == 0) return false;
     h.point = orig + dir * minDist;
-    int mat = 0;
+    const int mat = hitMaterialIndex<WIDE>(s, q, kind, index);
     if (kind == 1) {
         float4 sp;
-        if (WIDE && s.sphere_bvh) sp = s.spheres[index], mat = s.sphere_mat[index];
-        else sp = q.spheres[index], mat = q.sphere_mat[index];
+        if (WIDE && s.sphere_bvh) sp = s.spheres[index];
+        else sp = ldsFloat4(q.spheres + index);  // (see lightAt for the form)
         h.N = normalize(h.point - v3(sp.x, sp.y, sp.z));
     } else if (kind == 2) {
-        const float *t = triAt<WIDE>(s, q, index);
+        const Floats9 t = triAt<WIDE>(s, q, index);
         const V3 v0 = v3(t[0], t[1], t[2]), v1 = v3(t[3], t[4], t[5]), v2 = v3(t[6], t[7], t[8]);
         h.N = normalize(triNormalDir(v1 - v0, v2 - v0));
-        mat = triMatAt<WIDE>(s, q, index);
     } else if (kind == 3) {
-        const float *b = boxAt<WIDE>(s, q, index);
+        const Floats6 b = boxAt<WIDE>(s, q, index);
         const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
         h.N = normalize(boxNormalDir(lo, hi, h.point));
-        mat = boxMatAt<WIDE>(s, q, index);
     } else if (kind == 4) {
         const float4 *tp = s.mesh_tris + 3 * (size_t)index;
         const float4 p1 = tp[1], p2 = tp[2];
         h.N = normalize(triNormalDir(v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z)));
-        mat = s.mesh_mat;
     } else if (kind == 5) {
         h.N = v3(0.0f, 1.0f, 0.0f);
-        mat = s.water_mat;
     } else {
         h.N = v3(0.0f, 1.0f, 0.0f);
-        mat = s.island_mat;
     }
     h.m = materialAt<WIDE>(s, q, mat);
     h.mat_index = mat;

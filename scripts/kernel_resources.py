@@ -44,6 +44,28 @@ def kernel_resources(lib):
     return out
 
 
+def flat_instructions(lib):
+    """{kernel name: number of flat_* memory instructions} for the gfx950 code object in `lib`.  A flat access is what the
+    compiler emits when it no longer knows whether a pointer means LDS or device memory -- typically after merging an LDS
+    read and a global read into one load of a selected address; it is slower than either and waits for both memory pipes."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([LLVM + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+        asm = subprocess.check_output([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], text=True)
+    out, name = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            name = short_name(m.group(1))
+            if name:
+                out[name] = 0
+        elif name and re.match(r"\s+flat_", line):
+            out[name] += 1
+    return out
+
+
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "raytracing_amd", "librtx_hip.so")
     res = kernel_resources(lib)
@@ -52,3 +74,5 @@ if __name__ == "__main__":
         v = res[k]
         print("%-34s %5d %5d %11d %11d %8d %6d" % (k, v["vgpr_count"], v["sgpr_count"], v["vgpr_spill_count"], v["sgpr_spill_count"],
                                                    v["private_segment_fixed_size"], v["group_segment_fixed_size"]))
+    flat = {k: n for k, n in flat_instructions(lib).items() if n}
+    print("flat memory instructions:", flat if flat else "none")

@@ -41,3 +41,19 @@ def test_hot_kernels_keep_within_their_registers(resources, kernel):
     print(kernel, r)
     assert r["private_segment_fixed_size"] <= scratch and r["vgpr_spill_count"] <= spills, (kernel, r)
     assert r["vgpr_count"] <= vgprs
+
+
+def test_no_flat_memory_instructions_in_the_render_kernels():
+    """Every memory access of the kernels that trace rays says which memory it means (LDS, device memory, scratch).  A
+    flat_* instruction appears when the compiler merges an LDS read and a device-memory read into one load of a selected
+    address (the staged list entries and their tails in device memory, the frame heads in LDS and in scratch): it is
+    slower than either and makes the wave wait for both memory pipes.  It came and went with unrelated edits -- 2-4 % of a
+    3840x2160 frame -- until the staged reads were typed as LDS reads."""
+    import kernel_resources
+    lib = os.path.join(ROOT, "raytracing_amd", "librtx_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(kernel_resources.LLVM + "/llvm-objdump"):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    flat = kernel_resources.flat_instructions(lib)
+    render = {k: n for k, n in flat.items() if k.startswith(("k_render", "k_wf_", "k_trace_rays", "k_intersect_rays", "k_tile_probe"))}
+    assert render, sorted(flat)
+    assert not {k: n for k, n in render.items() if n}, render
