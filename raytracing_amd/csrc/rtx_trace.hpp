@@ -69,123 +69,164 @@ RTX_DEV int cellKey(const DevScene &s, int4 keys, V3 orig, V3 dir, V3 inv) {
     return key;
 }
 
+// One step of a walk over a tree of two-box nodes: tests the children of inner node `cur` against the ray (plane
+// distances t_lo = lo * ia + a, t_hi = hi * ib + b per axis; nothing beyond `bound` counts), goes to the nearer
+// child that is hit and pushes the other; kWalkDone when neither is hit and the stack is empty.  Box tests only
+// steer a walk; they use reciprocals and FMA freely.
+constexpr int kWalkDone = (int)0x80000000;
+RTX_DEV int walkPop(const int *stack, int stride, int &sp) {
+    int next = kWalkDone;
+    if (sp > 0) {
+        --sp;
+        next = stack[sp * stride];
+    }
+    return next;
+}
+RTX_DEV int walkStep(const BvhNode *nodes, int cur, float iax, float ibx, float iay, float iby, float iaz, float ibz, float ax, float bx,
+                     float ay, float by, float az, float bz, float bound, int *stack, int stride, int &sp) {
+    const float4 *np = reinterpret_cast<const float4 *>(nodes + cur);
+    const float4 a = np[0], b = np[1], c = np[2];
+    const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+    float tnL, tfL, tnR, tfR;
+    {
+        float t0 = __builtin_fmaf(a.x, iax, ax), t1 = __builtin_fmaf(a.w, ibx, bx);
+        float t2 = __builtin_fmaf(a.y, iay, ay), t3 = __builtin_fmaf(b.x, iby, by);
+        float t4 = __builtin_fmaf(a.z, iaz, az), t5 = __builtin_fmaf(b.y, ibz, bz);
+        tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+        tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+    }
+    {
+        float t0 = __builtin_fmaf(b.z, iax, ax), t1 = __builtin_fmaf(c.y, ibx, bx);
+        float t2 = __builtin_fmaf(b.w, iay, ay), t3 = __builtin_fmaf(c.z, iby, by);
+        float t4 = __builtin_fmaf(c.x, iaz, az), t5 = __builtin_fmaf(c.w, ibz, bz);
+        tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
+        tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+    }
+    const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
+    // near child (or the only one hit) next, the far one onto the stack; written without nested branches: the
+    // store is harmless when nothing is pushed (the slot is free)
+    const bool both = hitL && hitR;
+    const bool leftNext = hitL && (!hitR || tnL <= tnR);
+    stack[sp * stride] = leftNext ? ch.y : ch.x;
+    sp += both ? 1 : 0;
+    int next = leftNext ? ch.x : ch.y;
+    if (!(hitL || hitR)) next = walkPop(stack, stride, sp);
+    return next;
+}
+
+// The triangle of leaf `leaf` of the mesh's tree against the ray: Triangle::rayIntersect and the bookkeeping of the
+// reference's cell walk.  True: the walk is over (a hit nearer than t_exit: a shadow ray's occluder).
 template <bool STATS>
+RTX_DEV bool meshLeafTest(const DevScene &s, V3 orig, V3 dir, V3 inv, int leaf, float &best_t, int &best_tri, int &best_key, float t_exit,
+                          LaneCounters<STATS> &lc) {
+    const int ti = ~leaf;
+    const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
+    const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+    // fetched with the triangle, not after the test: a dependent load would double the latency
+    int4 keys = make_int4(-1, -1, -1, -1);
+    if (s.mesh_cells) keys = s.mesh_cells[ti];
+    RTX_COUNT(CNT_TRI_TESTS);
+    if constexpr (STATS) lc.v[CNT_TRI_TRIPS] += firstActiveLane() ? 1u : 0u;
+    float t = 0.0f;
+    bool past_u = false;
+    const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
+                           STATS ? &past_u : nullptr);
+    if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
+    if (th && t <= best_t) {
+        // The reference tests a triangle only for rays that pass (Cube::rayIntersect) a grid
+        // cell holding one of its vertices, and of two hits at the same distance it keeps the
+        // one its i,j,k cell walk reaches first.  key = that order (cell, position in the
+        // cell's list); kNoCell = the ray passes none of the triangle's cells.
+        int key = ti;
+        if (s.mesh_cells) {
+            key = kNoCell;
+            // Shortcut for the common case: the hit point lies well inside one of the
+            // triangle's cells, so the ray certainly passes that cell's box (the margin is
+            // orders of magnitude above the rounding of the slab test; directions with a
+            // component below the slab test's parallel threshold, far hits and exact ties
+            // take the long way).  The order key is then left open (kKeyOpen) and only
+            // worked out if a tie ever needs it.
+            if (t < best_t && t < s.grid_fast_tmax && fabsf(dir.x) >= kEps && fabsf(dir.y) >= kEps && fabsf(dir.z) >= kEps) {
+                const V3 p = orig + dir * t;
+                const float rx = (p.x - s.mesh_lo[0]) * s.grid_inv_step[0], ry = (p.y - s.mesh_lo[1]) * s.grid_inv_step[1],
+                            rz = (p.z - s.mesh_lo[2]) * s.grid_inv_step[2];
+                const float fx = floorf(rx), fy = floorf(ry), fz = floorf(rz);
+                const float lo_m = fminf(fminf(rx - fx, ry - fy), rz - fz), hi_m = fmaxf(fmaxf(rx - fx, ry - fy), rz - fz);
+                if (lo_m >= 1e-3f && hi_m <= 0.999f && fminf(fminf(fx, fy), fz) >= 0.0f && fmaxf(fmaxf(fx, fy), fz) <= 6.0f) {
+                    const int cell = ((int)fx * 7 + (int)fy) * 7 + (int)fz;
+                    if ((keys.x >= 0 && (keys.x >> 22) == cell) || (keys.y >= 0 && (keys.y >> 22) == cell) ||
+                        (keys.z >= 0 && (keys.z >> 22) == cell))
+                        key = kKeyOpen;
+                }
+            }
+            if (key == kNoCell) key = cellKey(s, keys, orig, dir, inv);
+        }
+        bool take = key != kNoCell && t < best_t;
+        if (key != kNoCell && t == best_t && best_tri >= 0) {  // a tie: both keys exactly
+            if (best_key == kKeyOpen) best_key = cellKey(s, s.mesh_cells[best_tri], orig, dir, inv);
+            take = key < best_key;
+        }
+        if (take) {
+            best_key = key;
+            best_t = t;
+            best_tri = ti;
+            if (t < t_exit) return true;
+        }
+    }
+    return false;
+}
+
+// DEFER picks the form of the walk.  false: two alternating phases, each a loop the whole wave runs together --
+// descend through inner nodes until this lane holds a leaf (lanes that found theirs idle until the rest have), then
+// one triangle test for every lane that holds one.  true: one loop in which a lane that comes upon a leaf keeps it
+// for later and walks on; the kept triangles are tested, by all lanes that hold one, when a lane holds one and
+// comes upon the next, or when no lane has an inner node left.  The winner is the smallest (distance, key) pair
+// whatever the order of the tests, and a test made later only lets the walk look at boxes that an earlier hit would
+// have culled.  The second form makes fewer, fuller node trips and more triangle trips: it is the faster one in the
+// level-by-level kernels (a wave of walkers only) and the slower one in k_render (measured: +4-7 % frame time).
+// `cur` >= 0 is an inner node, < 0 is leaf ~cur, kWalkDone means the stack ran dry.  A single-triangle mesh has an
+// inner root with one leaf.
+template <bool STATS, bool DEFER>
 RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &best_t, int &best_tri, float t_exit,
                            int *stack, int stride, LaneCounters<STATS> &lc) {
-    // Box tests only steer the walk; they use reciprocals and FMA freely.  Node boxes were padded
-    // when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test would
-    // accept is never culled by rounding here.
+    // Node boxes were padded when the tree was built, and t_far is widened by 2 ulp, so a triangle the exact test
+    // would accept is never culled by rounding here.
     const float ix = inv.x, iy = inv.y, iz = inv.z;  // clamped reciprocals: no inf - inf below
     const float ox = -orig.x * ix, oy = -orig.y * iy, oz = -orig.z * iz;
-    // Two alternating phases, each a loop the whole wave runs together: descend through inner
-    // nodes until this lane holds a leaf (lanes that found theirs idle until the rest have), then
-    // one triangle test for every lane that holds one.  `cur` >= 0 is an inner node, < 0 is leaf
-    // ~cur, kDone means the stack ran dry.  A single-triangle mesh has an inner root with one leaf.
-    constexpr int kDone = (int)0x80000000;
     int sp = 0;
     int cur = 0;
     int best_key = kNoCell;  // order in which the reference's walk reaches best_tri
-    for (;;) {
-        while (cur >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(s.bvh + cur);
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
-            RTX_COUNT(CNT_NODE_TESTS);
-            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            float tnL, tfL, tnR, tfR;
-            {
-                float t0 = __builtin_fmaf(a.x, ix, ox), t1 = __builtin_fmaf(a.w, ix, ox);
-                float t2 = __builtin_fmaf(a.y, iy, oy), t3 = __builtin_fmaf(b.x, iy, oy);
-                float t4 = __builtin_fmaf(a.z, iz, oz), t5 = __builtin_fmaf(b.y, iz, oz);
-                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
+    const auto step = [&]() {
+        RTX_COUNT(CNT_NODE_TESTS);
+        if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
+        cur = walkStep(s.bvh, cur, ix, ix, iy, iy, iz, iz, ox, ox, oy, oy, oz, oz, best_t, stack, stride, sp);
+    };
+    if constexpr (DEFER) {
+        int pend = kWalkDone;
+        for (;;) {
+            if (cur >= 0) step();
+            if (cur < 0 && cur != kWalkDone && pend == kWalkDone) {
+                pend = cur;
+                cur = walkPop(stack, stride, sp);
             }
-            {
-                float t0 = __builtin_fmaf(b.z, ix, ox), t1 = __builtin_fmaf(c.y, ix, ox);
-                float t2 = __builtin_fmaf(b.w, iy, oy), t3 = __builtin_fmaf(c.z, iy, oy);
-                float t4 = __builtin_fmaf(c.x, iz, oz), t5 = __builtin_fmaf(c.w, iz, oz);
-                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), best_t)) * 1.0000004f;
-            }
-            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
-            // near child (or the only one hit) next, the far one onto the stack; written without
-            // nested branches: the store is harmless when nothing is pushed (the slot is free)
-            const bool both = hitL && hitR;
-            const bool leftNext = hitL && (!hitR || tnL <= tnR);
-            stack[sp * stride] = leftNext ? ch.y : ch.x;
-            sp += both ? 1 : 0;
-            cur = leftNext ? ch.x : ch.y;
-            if (!(hitL || hitR)) {
-                cur = kDone;
-                if (sp > 0) {
-                    --sp;
-                    cur = stack[sp * stride];
+            if (__ballot(cur < 0 && cur != kWalkDone) != 0ull || __ballot(cur >= 0) == 0ull) {
+                if (pend != kWalkDone) {
+                    if (meshLeafTest<STATS>(s, orig, dir, inv, pend, best_t, best_tri, best_key, t_exit, lc)) return true;
+                    pend = kWalkDone;
                 }
             }
+            if (cur == kWalkDone && pend == kWalkDone) break;
         }
-        // the lanes that hold a leaf test it, and go on testing while what they pop is a leaf again
-        while (cur != kDone && cur < 0) {
-            const int ti = ~cur;
-            const float4 *tp = s.mesh_tris + 3 * (size_t)ti;
-            const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-            // fetched with the triangle, not after the test: a dependent load would double the latency
-            int4 keys = make_int4(-1, -1, -1, -1);
-            if (s.mesh_cells) keys = s.mesh_cells[ti];
-            RTX_COUNT(CNT_TRI_TESTS);
-            if constexpr (STATS) lc.v[CNT_TRI_TRIPS] += firstActiveLane() ? 1u : 0u;
-            float t = 0.0f;
-            bool past_u = false;
-            const bool th = triHit(v3(p0.x, p0.y, p0.z), v3(p1.x, p1.y, p1.z), v3(p2.x, p2.y, p2.z), orig, dir, t,
-                                   STATS ? &past_u : nullptr);
-            if constexpr (STATS) lc.v[CNT_TRI_FULL] += past_u ? 1u : 0u;
-            if (th && t <= best_t) {
-                // The reference tests a triangle only for rays that pass (Cube::rayIntersect) a grid
-                // cell holding one of its vertices, and of two hits at the same distance it keeps the
-                // one its i,j,k cell walk reaches first.  key = that order (cell, position in the
-                // cell's list); kNoCell = the ray passes none of the triangle's cells.
-                int key = ti;
-                if (s.mesh_cells) {
-                    key = kNoCell;
-                    // Shortcut for the common case: the hit point lies well inside one of the
-                    // triangle's cells, so the ray certainly passes that cell's box (the margin is
-                    // orders of magnitude above the rounding of the slab test; directions with a
-                    // component below the slab test's parallel threshold, far hits and exact ties
-                    // take the long way).  The order key is then left open (kKeyOpen) and only
-                    // worked out if a tie ever needs it.
-                    if (t < best_t && t < s.grid_fast_tmax && fabsf(dir.x) >= kEps && fabsf(dir.y) >= kEps && fabsf(dir.z) >= kEps) {
-                        const V3 p = orig + dir * t;
-                        const float rx = (p.x - s.mesh_lo[0]) * s.grid_inv_step[0], ry = (p.y - s.mesh_lo[1]) * s.grid_inv_step[1],
-                                    rz = (p.z - s.mesh_lo[2]) * s.grid_inv_step[2];
-                        const float fx = floorf(rx), fy = floorf(ry), fz = floorf(rz);
-                        const float lo_m = fminf(fminf(rx - fx, ry - fy), rz - fz), hi_m = fmaxf(fmaxf(rx - fx, ry - fy), rz - fz);
-                        if (lo_m >= 1e-3f && hi_m <= 0.999f && fminf(fminf(fx, fy), fz) >= 0.0f && fmaxf(fmaxf(fx, fy), fz) <= 6.0f) {
-                            const int cell = ((int)fx * 7 + (int)fy) * 7 + (int)fz;
-                            if ((keys.x >= 0 && (keys.x >> 22) == cell) || (keys.y >= 0 && (keys.y >> 22) == cell) ||
-                                (keys.z >= 0 && (keys.z >> 22) == cell))
-                                key = kKeyOpen;
-                        }
-                    }
-                    if (key == kNoCell) key = cellKey(s, keys, orig, dir, inv);
-                }
-                bool take = key != kNoCell && t < best_t;
-                if (key != kNoCell && t == best_t && best_tri >= 0) {  // a tie: both keys exactly
-                    if (best_key == kKeyOpen) best_key = cellKey(s, s.mesh_cells[best_tri], orig, dir, inv);
-                    take = key < best_key;
-                }
-                if (take) {
-                    best_key = key;
-                    best_t = t;
-                    best_tri = ti;
-                    if (t < t_exit) return true;
-                }
+    } else {
+        for (;;) {
+            while (cur >= 0) step();
+            // the lanes that hold a leaf test it, and go on testing while what they pop is a leaf again
+            while (cur != kWalkDone && cur < 0) {
+                if (meshLeafTest<STATS>(s, orig, dir, inv, cur, best_t, best_tri, best_key, t_exit, lc)) return true;
+                cur = walkPop(stack, stride, sp);
             }
-            cur = kDone;
-            if (sp > 0) {
-                --sp;
-                cur = stack[sp * stride];
-            }
+            if (cur == kWalkDone) break;
         }
-        if (cur == kDone) break;
     }
     return false;
 }
@@ -222,64 +263,68 @@ RTX_DEV float sphereReach(const DevScene &s, V3 orig, float t_exit) {
 template <bool STATS>
 RTX_DEV void sphereWalk(const DevScene &s, V3 orig, V3 dir, V3 inv, float reach, float t_exit, float &minDist, int &index,
                         int *stack, int stride, LaneCounters<STATS> &lc) {
-    const float ix = inv.x, iy = inv.y, iz = inv.z;
     float bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));  // no candidate's closest approach lies beyond
-    float delta = kSphereSlack * (bound + s.sphere_rmax);
-    // plane distances of the widened boxes: (lo - delta - o) * inv = lo * inv + a, (hi + delta - o) * inv = hi * inv + b
-    float ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
-    float ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
-    float az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
+    // Plane distances of the widened boxes, per axis t_lo = lo * ia + a and t_hi = hi * ib + b.  The widening a
+    // candidate needs grows with the distance of its closest approach, so the boxes are widened by
+    // kSphereSlack * (t + rmax) at ray parameter t instead of by the largest such value everywhere: the ray point
+    // o + t d lies inside the widened slab of an axis when  t (d + k) >= lo - k rmax - o  and  t (d - k) <= hi + k rmax - o,
+    // two half lines in t like those of the plain slab test, with the reciprocals of d + k and d - k in place of
+    // that of d.  (Where both bounds are negative -- the box lies behind the origin on this axis -- their order may
+    // be the other way round; the interval then ends below zero either way.)  An axis the ray runs almost parallel
+    // to (|d| <= 2 k: d - k and d + k differ in sign or nearly vanish) gets the uniform widening by the largest value,
+    // (lo - delta - o) * inv = lo * inv + a and (hi + delta - o) * inv = hi * inv + b.  Measured on 10 000 spheres:
+    // 4 % fewer node tests and 23 % fewer sphere tests than uniform widening on all axes.
+    float iax, ax, ibx, bx, iay, ay, iby, by, iaz, az, ibz, bz;
+    {
+        const float k = kSphereSlack, kr = kSphereSlack * s.sphere_rmax, delta = kSphereSlack * (bound + s.sphere_rmax);
+        const auto axis = [&](float o, float d, float iv, float &ia, float &a, float &ib, float &b) {
+            if (fabsf(d) > 2.0f * k) {
+                ia = __builtin_amdgcn_rcpf(d + k), ib = __builtin_amdgcn_rcpf(d - k);
+                a = -(o + kr) * ia, b = -(o - kr) * ib;
+            } else {
+                ia = ib = iv;
+                a = -(o + delta) * iv, b = -(o - delta) * iv;
+            }
+        };
+        axis(orig.x, dir.x, inv.x, iax, ax, ibx, bx);
+        axis(orig.y, dir.y, inv.y, iay, ay, iby, by);
+        axis(orig.z, dir.z, inv.z, iaz, az, ibz, bz);
+    }
     int sp = 0;
-    int cur = 0;  // >= 0 inner node, < 0 sphere ~cur
+    int cur = 0;            // >= 0 inner node, < 0 sphere ~cur, kWalkDone: nothing left
+    int pend = kWalkDone;   // a sphere whose test is put off
     for (;;) {
         if (cur >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(s.sphere_bvh + cur);
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
             RTX_COUNT(CNT_NODE_TESTS);
             if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            float tnL, tfL, tnR, tfR;
-            {
-                float t0 = __builtin_fmaf(a.x, ix, ax), t1 = __builtin_fmaf(a.w, ix, bx);
-                float t2 = __builtin_fmaf(a.y, iy, ay), t3 = __builtin_fmaf(b.x, iy, by);
-                float t4 = __builtin_fmaf(a.z, iz, az), t5 = __builtin_fmaf(b.y, iz, bz);
-                tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-                tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
-            }
-            {
-                float t0 = __builtin_fmaf(b.z, ix, ax), t1 = __builtin_fmaf(c.y, ix, bx);
-                float t2 = __builtin_fmaf(b.w, iy, ay), t3 = __builtin_fmaf(c.z, iy, by);
-                float t4 = __builtin_fmaf(c.x, iz, az), t5 = __builtin_fmaf(c.w, iz, bz);
-                tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-                tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
-            }
-            const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
-            const bool both = hitL && hitR;
-            const bool leftNext = hitL && (!hitR || tnL <= tnR);
-            stack[sp * stride] = leftNext ? ch.y : ch.x;
-            sp += both ? 1 : 0;
-            cur = leftNext ? ch.x : ch.y;
-            if (hitL || hitR) continue;
-        } else {
-            const int i = ~cur;
-            const float4 sph = s.spheres[i];
-            RTX_COUNT(CNT_SPHERE_TESTS);
-            float curDist = 0.0f;
-            if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) &&
-                (curDist < minDist || (curDist == minDist && i < index))) {
-                minDist = curDist;
-                index = i;
-                if (curDist < t_exit) return;
-                bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));
-                delta = kSphereSlack * (bound + s.sphere_rmax);
-                ax = -(orig.x + delta) * ix, bx = -(orig.x - delta) * ix;
-                ay = -(orig.y + delta) * iy, by = -(orig.y - delta) * iy;
-                az = -(orig.z + delta) * iz, bz = -(orig.z - delta) * iz;
+            cur = walkStep(s.sphere_bvh, cur, iax, ibx, iay, iby, iaz, ibz, ax, bx, ay, by, az, bz, bound, stack, stride, sp);
+        }
+        // A lane that comes upon a leaf keeps it for later and walks on.  The kept spheres are tested, by all lanes
+        // that hold one, when a lane holds one and comes upon the next, or when no lane has an inner node left: the
+        // sphere test then runs for some twenty lanes instead of eight per trip, and the lanes that used to wait for
+        // it walk (10 000 spheres: 116.6 -> 104.2 ms a frame).  The result is the nearest hit, the lowest index among
+        // equals, whatever the order of the tests; a test made later only lets the walk look at boxes that an earlier
+        // hit would have culled.
+        if (cur < 0 && cur != kWalkDone && pend == kWalkDone) {
+            pend = cur;
+            cur = walkPop(stack, stride, sp);
+        }
+        if (__ballot(cur < 0 && cur != kWalkDone) != 0ull || __ballot(cur >= 0) == 0ull) {
+            if (pend != kWalkDone) {
+                const int i = ~pend;
+                pend = kWalkDone;
+                const float4 sph = s.spheres[i];
+                RTX_COUNT(CNT_SPHERE_TESTS);
+                float curDist = 0.0f;
+                if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
+                    minDist = curDist;
+                    index = i;
+                    if (curDist < t_exit) return;
+                    bound = fminf(reach, 1.01f * (minDist + s.sphere_rmax));
+                }
             }
         }
-        if (sp == 0) return;
-        --sp;
-        cur = stack[sp * stride];
+        if (cur == kWalkDone && pend == kWalkDone) return;
     }
 }
 
@@ -385,11 +430,11 @@ RTX_DEV bool castBegin(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, 
     return s.n_mesh_tris > 0 && !(minDist < t_exit) && meshGate<STATS>(s, orig, dir, inv, lc);
 }
 
-template <bool STATS>
+template <bool STATS, bool DEFER = false>
 RTX_DEV void castMesh(const DevScene &s, V3 orig, V3 dir, float t_exit, CastState &cs, int *stack, int stride, LaneCounters<STATS> &lc) {
     int tri = -1;
     float t = cs.minDist;
-    meshIntersect<STATS>(s, orig, dir, safeInverse(dir), t, tri, t_exit, stack, stride, lc);
+    meshIntersect<STATS, DEFER>(s, orig, dir, safeInverse(dir), t, tri, t_exit, stack, stride, lc);
     if (tri >= 0) cs.minDist = t, cs.kind = 4, cs.index = tri;
 }
 
@@ -498,11 +543,12 @@ RTX_DEV bool castEnd(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bo
     return minDist < s.far_clip;
 }
 
-template <bool STATS, bool WIDE = false>
+// (DEFER: the form of the mesh walk, see meshIntersect)
+template <bool STATS, bool WIDE = false, bool DEFER = false>
 RTX_DEV bool sceneIntersect(const DevScene &s, const SmallScene &q, V3 orig, V3 dir, bool shadow, float t_exit, Hit &h,
                             float &min_dist, int *stack, int stride, LaneCounters<STATS> &lc) {
     CastState cs;
-    if (castBegin<STATS, WIDE>(s, q, orig, dir, t_exit, cs, stack, stride, lc)) castMesh<STATS>(s, orig, dir, t_exit, cs, stack, stride, lc);
+    if (castBegin<STATS, WIDE>(s, q, orig, dir, t_exit, cs, stack, stride, lc)) castMesh<STATS, DEFER>(s, orig, dir, t_exit, cs, stack, stride, lc);
     return castEnd<STATS, WIDE>(s, q, orig, dir, shadow, t_exit, cs, h, min_dist, lc);
 }
 

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_trace(D
         Hit h;
         float md = 0.0f;
         bool hit = false;
-        if (casts) hit = sceneIntersect<STATS, WIDE>(s, q, orig, dir, false, -1.0f, h, md, stack, kBlock, lc);
+        if (casts) hit = sceneIntersect<STATS, WIDE, true>(s, q, orig, dir, false, -1.0f, h, md, stack, kBlock, lc);
         if (valid && !hit) {
             RTX_COUNT(CNT_SKY);
             wfDeliver(a.parent, level, link, skyColor(s, dir));
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(
         RTX_COUNT(CNT_SHADOW);
         Hit h;
         float md = 0.0f;
-        const bool hit = sceneIntersect<STATS, WIDE>(s, q, st.orig, st.dir, true, st.t_exit, h, md, stack, kBlock, lc);
+        const bool hit = sceneIntersect<STATS, WIDE, true>(s, q, st.orig, st.dir, true, st.t_exit, h, md, stack, kBlock, lc);
         if (pathShadowed(st, hit, md)) atomicOr(reinterpret_cast<unsigned *>(a.fat + 4 * (size_t)node + 1) + 3, 1u << li);
     }
     flushCounters<STATS>(lc, counters);

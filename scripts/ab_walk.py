@@ -36,6 +36,6 @@ for wl in names.split(","):
         st = ctx.render(B.default_camera(), w, h, d, want_stats=True)[1]
         ctx.close()
         rays = max(st.rays, 1)
-        print("%-24s %-9s median %9.3f ms  min %9.3f | rays %.3e node tests/ray %.2f tri tests/ray %.2f sphere tests/ray %.2f lanes/node trip %.1f lanes/tri trip %.1f"
+        print("%-24s %-9s median %9.3f ms  min %9.3f | rays %.3e node tests/ray %.2f tri tests/ray %.2f sphere tests/ray %.2f lanes/node trip %.1f lanes/tri trip %.1f | node trips %.3e tri trips %.3e"
               % (name, wl, statistics.median(ms[min(3, n - 1):]), min(ms[min(3, n - 1):]), rays, st.bvh_node_tests / rays, st.triangle_tests / rays,
-                 st.sphere_tests / rays, st.bvh_node_tests / max(st.node_wave_trips, 1), st.triangle_tests / max(st.tri_wave_trips, 1)), flush=True)
+                 st.sphere_tests / rays, st.bvh_node_tests / max(st.node_wave_trips, 1), st.triangle_tests / max(st.tri_wave_trips, 1), st.node_wave_trips, st.tri_wave_trips), flush=True)
