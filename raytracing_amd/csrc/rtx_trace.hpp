@@ -248,7 +248,10 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
 // matter beyond the far side of the box around all spheres, nor (once a hit is known) beyond that
 // hit's distance plus a radius.
 // ---------------------------------------------------------------------------------------------
-constexpr float kSphereSlack = 1.2e-3f;  // > sqrt(18 * 2^-24) = 1.04e-3
+#ifndef RTX_SPHERE_SLACK  // (a build with a smaller value must fail the grazing-ray tests)
+#define RTX_SPHERE_SLACK 1.2e-3f
+#endif
+constexpr float kSphereSlack = RTX_SPHERE_SLACK;  // > sqrt(18 * 2^-24) = 1.04e-3
 
 // Largest closest-approach distance that can matter for a ray from `orig` (no hit known yet): the far
 // side of the box around all spheres, and for a shadow ray (t_exit > 0, just short of the light's

@@ -90,6 +90,55 @@ def test_many_spheres_equal_the_oracle(hip, oracle_backend, textures, n):
         assert np.array_equal(f, frames[0])
 
 
+def _grazing_rays(c, r, n, seed):
+    """Rays that pass a sphere's centre at about its radius, from origins 50 to 3000 units away: the distance
+    from the centre is sqrt(r^2 + q * 1e-6 * L^2), q in [-1, 1.3] -- the band in which the rounding of the
+    reference's sphere test (about 1.07e-6 L^2 in the squared distance) decides -- and half of the origins lie
+    along a coordinate axis from their target, within a few thousandths, so that one or two direction
+    components are tiny, zero or change sign."""
+    rng = np.random.default_rng(seed)
+    i = rng.integers(0, len(c), n)
+    cc, rr = c[i].astype(np.float64), r[i].astype(np.float64)
+    L = np.exp(rng.uniform(np.log(50.0), np.log(3000.0), n))
+    u = rng.normal(size=(n, 3))
+    axis = rng.integers(0, 3, n)
+    along = rng.random(n) < 0.5
+    e = np.zeros((n, 3))
+    e[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    tiny = rng.choice([0.0, 1e-4, 1.2e-3, 2.4e-3, 5e-3], (n, 3)) * rng.choice([-1.0, 1.0], (n, 3))
+    tiny[np.arange(n), axis] = 0.0
+    u[along] = (e + tiny)[along]
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = cc - u * L[:, None]                        # the ray o + t u passes through the centre ...
+    v = np.cross(u, rng.normal(size=(n, 3)))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    q = rng.uniform(-1.0, 1.3, n)
+    d2 = np.maximum(rr * rr + q * 1e-6 * L * L, 0.0)
+    target = cc + v * np.sqrt(d2)[:, None]         # ... and this one passes it at sqrt(d2)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+
+
+@pytest.mark.parametrize("n", [40, 3000])
+def test_grazing_rays_from_far_origins_equal_the_oracle(hip, oracle_backend, textures, n):
+    """What the sphere tree's walk may cull depends on the rounding of the reference's sphere test, which grows
+    with the distance to the sphere: rays from far away that graze small spheres, many of them almost parallel
+    to an axis, hit exactly what the loop over all spheres hits."""
+    c, r, m = _sphere_cloud(n, 7 * n)
+    r[::3] = 0.02
+    rays = [_grazing_rays(c, r, 30000, 11), _grazing_rays(c, r, 30000, 12)]
+    out = []
+    for b in (oracle_backend, hip):
+        ctx = make_default_context(b, textures, mask=31 & ~1, commit=False)
+        ctx.set_spheres(c, r, m)
+        ctx.commit()
+        out.append([ctx.intersect_rays(o, d) for o, d in rays])
+    for a, g in zip(out[0], out[1]):
+        assert (a[:, 0] > 0).sum() > 1000
+        assert np.array_equal(a.view(np.uint32), g.view(np.uint32))
+
+
 def test_sphere_list_order_decides_ties(hip, oracle_backend, textures):
     """Twenty copies of one sphere, each with its own material: the first one in the list is the one hit."""
     mats = np.tile(hip.default_materials()[:1], (20, 1))
