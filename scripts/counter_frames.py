@@ -1,7 +1,9 @@
 """Renders FRAMES frames of one bench workload through the C ABI and nothing else (no torch: starts in a second).
 bench.py runs it under `rocprofv3 --pmc ...`, one counter group per run, and reads the counters of the render
 kernels from the CSV.  usage: python3 scripts/counter_frames.py <workload> [frames] [library]
-(RTX_COUNTER_OPTS="8=0,7=0" in the environment sets options of the context: id=value pairs of rtx_set_option)"""
+(RTX_COUNTER_OPTS="8=0,7=0" in the environment sets options of the context: id=value pairs of rtx_set_option;
+for the stress workloads RTX_STRESS_LEVELS=n subdivides the mesh n times instead of four and RTX_STRESS_SKY=k keeps every
+k-th row and column of the panorama -- to see what part of the traffic is the mesh and what part the panorama)"""
 import os
 import sys
 
@@ -18,7 +20,11 @@ w, h, depth, mask = bench.WORKLOADS[name][:4]
 water, sky = H.decode_jpeg(ASSETS_DIR + "/water.jpg"), H.decode_jpeg(ASSETS_DIR + "/envmap.jpg")
 ctx = H.create()
 if name.startswith("stress"):
-    scenes.load_stress_scene(ctx, H, water, sky)
+    k = int(os.environ.get("RTX_STRESS_SKY", "1"))
+    if k > 1:
+        import numpy as np
+        sky = np.ascontiguousarray(sky[::k, ::k])
+    scenes.load_stress_scene(ctx, H, water, sky, levels=int(os.environ.get("RTX_STRESS_LEVELS", "4")))
 else:
     ctx.load_default_scene(water, sky, mask=mask)
 for pair in filter(None, os.environ.get("RTX_COUNTER_OPTS", "").split(",")):

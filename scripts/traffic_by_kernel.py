@@ -4,7 +4,7 @@ pass for FETCH_SIZE and one for WRITE_SIZE (they do not fit one pass), summed pe
 number of frames.  FETCH_SIZE counts kilobytes and tallies a 128-byte read request as 64 bytes on gfx950: doubled
 here, as bench.py does; WRITE_SIZE (kilobytes) as it is.
 
-    python scripts/traffic_by_kernel.py [workload] [frames] [variant]
+    python scripts/traffic_by_kernel.py [workload] [frames] [library]
 
 `variant` is passed on in RTX_VARIANT for builds that read it."""
 import csv
@@ -28,7 +28,7 @@ def main():
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(base, counter)
         cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", counter, "-d", d, "-o", "c", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "scripts", "counter_frames.py"), workload, str(frames)]
+               sys.executable, os.path.join(ROOT, "scripts", "counter_frames.py"), workload, str(frames)] + sys.argv[3:4]
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=260)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
