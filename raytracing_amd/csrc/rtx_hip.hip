@@ -856,7 +856,8 @@ struct WfMem {
     WfPlan plan;
     WfCounters *counters = nullptr;
     float4 *ray_o[kWfLevels + 1] = {}, *ray_d[kWfLevels + 1] = {}, *thin[kWfLevels + 1] = {};
-    float4 *fat = nullptr, *samples = nullptr;
+    float4 *pt = nullptr, *nrm = nullptr, *vw = nullptr, *dif = nullptr, *samples = nullptr;
+    unsigned *hidden = nullptr;
     unsigned *shadow_q = nullptr;
 };
 
@@ -1335,7 +1336,7 @@ WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
         }
     }
     if (strip >= (size_t)kWfMaxIndex) p.fits = false;
-    bytes += fat_entries * (4 * sizeof(float4) + nl * sizeof(unsigned)) + 1024;  // fat records, shadow lists
+    bytes += fat_entries * (4 * sizeof(float4) + sizeof(unsigned) + nl * sizeof(unsigned)) + 2048;  // fat records, shadow lists
     p.bytes = bytes;
     return p;
 }
@@ -1384,7 +1385,7 @@ int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
     w.strip_samples = strip, w.depth = D, w.n_lights = nl;
     w.plan = plan;
     for (int l = 0; l <= kWfLevels; ++l) w.ray_o[l] = w.ray_d[l] = w.thin[l] = nullptr;
-    w.fat = nullptr, w.shadow_q = nullptr;
+    w.pt = w.nrm = w.vw = w.dif = nullptr, w.hidden = nullptr, w.shadow_q = nullptr;
     unsigned char *p = static_cast<unsigned char *>(w.block);
     auto take = [&](size_t n) {
         unsigned char *q = p;
@@ -1403,7 +1404,11 @@ int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
         }
     }
     if (D > 0) {
-        w.fat = reinterpret_cast<float4 *>(take(fat_entries * 4 * sizeof(float4)));
+        w.pt = reinterpret_cast<float4 *>(take(fat_entries * sizeof(float4)));
+        w.nrm = reinterpret_cast<float4 *>(take(fat_entries * sizeof(float4)));
+        w.vw = reinterpret_cast<float4 *>(take(fat_entries * sizeof(float4)));
+        w.dif = reinterpret_cast<float4 *>(take(fat_entries * sizeof(float4)));
+        w.hidden = reinterpret_cast<unsigned *>(take(fat_entries * sizeof(unsigned)));
         w.shadow_q = reinterpret_cast<unsigned *>(take(fat_entries * (size_t)(nl > 0 ? nl : 1) * sizeof(unsigned)));
     }
     if ((size_t)(p - static_cast<unsigned char *>(w.block)) > w.block_bytes) {
@@ -1421,7 +1426,7 @@ WfArgs wfArgs(const WfMem &w, int l, int launch) {
     a.next_req = WfList{w.counters->n[0][l + 1], w.plan.req_cap[l + 1], 2 * kWfSub};
     a.work = w.counters->work[launch][l];
     a.ray_o = w.ray_o[l], a.ray_d = w.ray_d[l], a.next_o = w.ray_o[l + 1], a.next_d = w.ray_d[l + 1];
-    a.fat = w.fat, a.shadow_q = w.shadow_q, a.thin = w.thin[l], a.parent = l == 0 ? w.samples : w.thin[l - 1];
+    a.pt = w.pt, a.nrm = w.nrm, a.vw = w.vw, a.dif = w.dif, a.hidden = w.hidden, a.shadow_q = w.shadow_q, a.thin = w.thin[l], a.parent = l == 0 ? w.samples : w.thin[l - 1];
     a.level = l;
     return a;
 }

@@ -72,9 +72,12 @@ struct WfStrip {
 };
 
 // Records of one node, in float4 so that every access is one 16-byte load or store.
-//   fat  (4 x float4, lives from the level's trace launch to its shade launch, one array for all levels):
-//        [0] point.xyz, material index   [1] N.xyz, hidden mask (k_wf_shadow ORs into it)
-//        [2] view.xyz, cast mask         [3] diffuse.rgb (after water / island override), link to the parent
+//   fat  (lives from the level's trace launch to its shade launch, one set of arrays for all levels; an array per
+//        field, so that the lanes of a wave -- neighbouring nodes -- read and write whole cache lines, and k_wf_shadow,
+//        which wants the first two fields only, fetches nothing else):
+//        pt  point.xyz, material index   nrm  N.xyz, cast mask
+//        vw  view.xyz                    dif  diffuse.rgb (after water / island override), link to the parent
+//        hidden  one word: the lights found hidden (k_wf_shadow ORs into it; a cache line holds 32 nodes' words)
 //   thin (3 x float4, one array per level, lives until the level is resolved):
 //        [0] own colour.rgb, a2          [1] reflect child's colour.rgb, a3
 //        [2] refract child's colour.rgb, link to the parent | kHasRefl | kHasRefr
@@ -83,7 +86,8 @@ struct WfArgs {
     unsigned *work;                        // this launch's chunk hand-out counters
     const float4 *ray_o, *ray_d;           // this level's requests: orig.xyz + link, dir.xyz
     float4 *next_o, *next_d;               // the next level's
-    float4 *fat;
+    float4 *pt, *nrm, *vw, *dif;
+    unsigned *hidden;
     unsigned *shadow_q;
     float4 *thin;                          // this level's thin records
     float4 *parent;                        // the level above's thin records, or the strip's sample colours (level 0)
@@ -283,11 +287,11 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_trace(D
         s1 = (k + 1u) * a.shadows.sub_cap - 1u - (unsigned)__builtin_amdgcn_readfirstlane((int)s1);  // the second class fills its region backwards
         const unsigned node = k * a.nodes.sub_cap + node_at + lanesBelow(mn);
         if (node_here) {
-            float4 *f = a.fat + 4 * (size_t)node;
-            f[0] = make_float4(h.point.x, h.point.y, h.point.z, __int_as_float(h.mat_index));
-            f[1] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(0u));
-            f[2] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(cast_mask));
-            f[3] = make_float4(h.m.dr, h.m.dg, h.m.db, __uint_as_float(link));
+            a.pt[node] = make_float4(h.point.x, h.point.y, h.point.z, __int_as_float(h.mat_index));
+            a.nrm[node] = make_float4(h.N.x, h.N.y, h.N.z, __uint_as_float(cast_mask));
+            a.vw[node] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            a.dif[node] = make_float4(h.m.dr, h.m.dg, h.m.db, __uint_as_float(link));
+            a.hidden[node] = 0u;
         }
         // in the lists the requests stand light by light, so that the lanes of a wave of k_wf_shadow aim at one
         // light from neighbouring points
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(
         if (!valid) continue;
         const unsigned e = a.shadow_q[i];
         const unsigned node = e >> 5, li = e & 31u;
-        const float4 f0 = a.fat[4 * (size_t)node], f1 = a.fat[4 * (size_t)node + 1];
+        const float4 f0 = a.pt[node], f1 = a.nrm[node];
         PathState st;
         st.point = v3(f0.x, f0.y, f0.z), st.N = v3(f1.x, f1.y, f1.z);
         // the same three values aimLight produced when the request was made (src/Scene.cpp:65)
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(
         Hit h;
         float md = 0.0f;
         const bool hit = sceneIntersect<STATS, WIDE, true>(s, q, st.orig, st.dir, true, st.t_exit, h, md, stack, kBlock, lc);
-        if (pathShadowed(st, hit, md)) atomicOr(reinterpret_cast<unsigned *>(a.fat + 4 * (size_t)node + 1) + 3, 1u << li);
+        if (pathShadowed(st, hit, md)) atomicOr(a.hidden + node, 1u << li);
     }
     flushCounters<STATS>(lc, counters);
 }
@@ -358,13 +362,13 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
         bool doRefl = false, doRefr = false;
         V3 reflO = v3(0, 0, 0), reflD = v3(0, 0, 1), refrO = v3(0, 0, 0), refrD = v3(0, 0, 1);
         if (valid) {
-            const float4 f0 = a.fat[4 * (size_t)i], f1 = a.fat[4 * (size_t)i + 1], f2 = a.fat[4 * (size_t)i + 2], f3 = a.fat[4 * (size_t)i + 3];
+            const float4 f0 = a.pt[i], f1 = a.nrm[i], f2 = a.vw[i], f3 = a.dif[i];
             PathState st;
             st.point = v3(f0.x, f0.y, f0.z), st.N = v3(f1.x, f1.y, f1.z), st.view = v3(f2.x, f2.y, f2.z);
             st.m = materialAt<WIDE>(s, q, __float_as_int(f0.w));
             st.m.dr = f3.x, st.m.dg = f3.y, st.m.db = f3.z;
             st.Ld = 0.0f, st.Ls = 0.0f;
-            const unsigned lit = __float_as_uint(f2.w) & ~__float_as_uint(f1.w);  // cast and not hidden
+            const unsigned lit = __float_as_uint(f1.w) & ~a.hidden[i];  // cast and not hidden
             const unsigned link = __float_as_uint(f3.w);
             // calcLightning's sums in light order, src/Scene.cpp:73-78
             for (int li = 0; li < s.n_lights; ++li) {

@@ -3,7 +3,8 @@ bench.py runs it under `rocprofv3 --pmc ...`, one counter group per run, and rea
 kernels from the CSV.  usage: python3 scripts/counter_frames.py <workload> [frames] [library]
 (RTX_COUNTER_OPTS="8=0,7=0" in the environment sets options of the context: id=value pairs of rtx_set_option;
 for the stress workloads RTX_STRESS_LEVELS=n subdivides the mesh n times instead of four and RTX_STRESS_SKY=k keeps every
-k-th row and column of the panorama -- to see what part of the traffic is the mesh and what part the panorama)"""
+k-th row and column of the panorama, RTX_STRESS_WATER=k of the water texture -- to see what part of the traffic is the mesh
+and what part the textures)"""
 import os
 import sys
 
@@ -24,6 +25,10 @@ if name.startswith("stress"):
     if k > 1:
         import numpy as np
         sky = np.ascontiguousarray(sky[::k, ::k])
+    k = int(os.environ.get("RTX_STRESS_WATER", "1"))
+    if k > 1:
+        import numpy as np
+        water = np.ascontiguousarray(water[::k, ::k])
     scenes.load_stress_scene(ctx, H, water, sky, levels=int(os.environ.get("RTX_STRESS_LEVELS", "4")))
 else:
     ctx.load_default_scene(water, sky, mask=mask)
