@@ -921,7 +921,7 @@ struct rtx_ctx {
     int lds_frame_slots[4] = {0, 0, 0, 0};  // frame heads of a lane that k_render keeps in LDS, per variant
     int sphere_bvh_depth = 0;
     int wf_blocks[3][4] = {};               // resident blocks of k_wf_trace / k_wf_shadow [STATS + 2 * WIDE], k_wf_shade [STATS]
-    size_t wf_budget = (size_t)16 << 30;    // bytes the pipeline's arrays may take
+    size_t wf_budget = (size_t)64 << 30;    // bytes the pipeline's arrays may take
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
     HostStage stage;                        // rtx_render's way to the caller's host buffer (RTX_OPT_PIN_OUTPUT)
@@ -1315,6 +1315,13 @@ int wavefrontBlocks(rtx_ctx *c) {
     return RTX_OK;
 }
 
+// bits that hold a light's number in a shadow request
+unsigned wfLightBits(int n_lights) {
+    unsigned bits = 1;
+    while ((1 << bits) < n_lights) ++bits;
+    return bits;
+}
+
 WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
     WfPlan p;
     const size_t nl = (size_t)(n_lights > 0 ? n_lights : 1);
@@ -1325,7 +1332,9 @@ WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
         const size_t node_chunks = (size_t)kWfSub * (node_cap / kWfChunk);
         const size_t req_cap = (node_chunks / kWfSub + 1) * kWfChunk * 2;  // two children per node
         p.node_cap[l] = (unsigned)node_cap, p.shadow_cap[l] = (unsigned)(node_cap * nl);
-        if (kWfSub * node_cap >= ((size_t)1 << 27) || kWfSub * node_cap * nl >= 0xffffffffull) p.fits = false;
+        // a node's index shares the 32 bits of a shadow request with the light's number and must fit a link's 28
+        if (kWfSub * node_cap >= std::min<size_t>((size_t)1 << (32 - wfLightBits(n_lights)), (size_t)kWfMaxIndex) || kWfSub * node_cap * nl >= 0xffffffffull)
+            p.fits = false;
         fat_entries = std::max(fat_entries, kWfSub * node_cap);
         if (l + 1 < D) {
             p.req_cap[l + 1] = (unsigned)req_cap;
@@ -1428,6 +1437,7 @@ WfArgs wfArgs(const WfMem &w, int l, int launch) {
     a.ray_o = w.ray_o[l], a.ray_d = w.ray_d[l], a.next_o = w.ray_o[l + 1], a.next_d = w.ray_d[l + 1];
     a.pt = w.pt, a.nrm = w.nrm, a.vw = w.vw, a.dif = w.dif, a.hidden = w.hidden, a.shadow_q = w.shadow_q, a.thin = w.thin[l], a.parent = l == 0 ? w.samples : w.thin[l - 1];
     a.level = l;
+    a.light_bits = wfLightBits(w.n_lights);
     return a;
 }
 

@@ -30,11 +30,11 @@
 // pathAddLight, skyColor ...), in the same order per node: frames are byte-identical.
 
 constexpr int kWfLevels = kMaxDepth;
-constexpr unsigned kLinkIndex = 0x0fffffffu;  // bits 0..27: index of the parent's record (or of the sample, level 0)
-constexpr unsigned kLinkRefr = 1u << 28;      // the request is the parent's refract child (else its reflect child)
-constexpr unsigned kHasRefl = 1u << 29, kHasRefr = 1u << 30;  // thin record: which children were traced
+constexpr unsigned kLinkIndex = 0x1fffffffu;  // bits 0..28: index of the parent's record (or of the sample, level 0)
+constexpr unsigned kLinkRefr = 1u << 29;      // the request is the parent's refract child (else its reflect child)
+constexpr unsigned kHasRefl = 1u << 30, kHasRefr = 1u << 31;  // thin record: which children were traced
 constexpr unsigned kWfMaxIndex = kLinkIndex;
-constexpr int kWfMaxLights = 32;              // bits of the cast / hidden masks; shadow request = node << 5 | light
+constexpr int kWfMaxLights = 32;              // bits of the cast / hidden masks; shadow request = node << light_bits | light
 
 // Every list (trace requests, nodes, shadow requests of a level) is a set of sub-lists, each with its own
 // length counter in a cache line of its own: atomics on a single address go one after the other at about
@@ -92,6 +92,7 @@ struct WfArgs {
     float4 *thin;                          // this level's thin records
     float4 *parent;                        // the level above's thin records, or the strip's sample colours (level 0)
     int level;
+    unsigned light_bits;                   // bits of a shadow request that hold the light's number (as many as the scene's lights need)
 };
 
 RTX_DEV unsigned laneId() { return __builtin_amdgcn_mbcnt_hi(0xffffffffu, __builtin_amdgcn_mbcnt_lo(0xffffffffu, 0u)); }
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_trace(D
             for (int li = 0; li < s.n_lights; ++li) {
                 const bool c0 = ((cast_mask & mesh_mask) >> li) & 1u, c1 = ((cast_mask & ~mesh_mask) >> li) & 1u;
                 const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-                if (c0) a.shadow_q[s0 + lanesBelow(m0)] = (node << 5) | (unsigned)li;
-                if (c1) a.shadow_q[s1 - lanesBelow(m1)] = (node << 5) | (unsigned)li;
+                if (c0) a.shadow_q[s0 + lanesBelow(m0)] = (node << a.light_bits) | (unsigned)li;
+                if (c1) a.shadow_q[s1 - lanesBelow(m1)] = (node << a.light_bits) | (unsigned)li;
                 s0 += (unsigned)__popcll(m0), s1 -= (unsigned)__popcll(m1);
             }
         }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? 5 : 4) void k_wf_shadow(
         const bool valid = wfChunkEntry(ch, a.shadows, chunk, i);
         if (!valid) continue;
         const unsigned e = a.shadow_q[i];
-        const unsigned node = e >> 5, li = e & 31u;
+        const unsigned node = e >> a.light_bits, li = e & ((1u << a.light_bits) - 1u);
         const float4 f0 = a.pt[node], f1 = a.nrm[node];
         PathState st;
         st.point = v3(f0.x, f0.y, f0.z), st.N = v3(f1.x, f1.y, f1.z);
