@@ -138,6 +138,9 @@ enum rtx_option {
                                  65536: an MI355X has 288 GB, and larger strips mean fewer launches with their
                                  ramps and tails -- 10 000 spheres at 4096 x 4096 x 4 samples: 97.0 ms within
                                  16 GiB, 92.5 within 64); a frame that needs more is traced in strips of tiles */
+    RTX_OPT_RAY_POOL = 15,    /* 0/1 (default 1): in the level-by-level pipeline of a scene whose spheres sit behind a
+                                 tree, the lanes of a wave draw their shadow rays from the list one by one as they
+                                 finish, instead of working through 64 of them in step (same rays, same results) */
     RTX_OPT_TILE_PROBE = 13,  /* 0/1 (default 0): the first frame of a view (no costs of a previous frame to go by) puts
                                  its tiles into classes by one probe ray per tile through sceneIntersect (what it hits,
                                  where the children of that hit go) on top of the projected bounding boxes of the mesh

@@ -598,6 +598,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
         case RTX_OPT_PIN_OUTPUT: break;  // no device to copy from
         case RTX_OPT_TILE_PROBE: break;  // no tile schedule here
         case RTX_OPT_QUAD_KERNEL: break;
+        case RTX_OPT_RAY_POOL: break;  // no waves here
         case RTX_OPT_SPP:
             if (value != 1 && value != 4) return fail(RTX_E_INVALID, "RTX_OPT_SPP: 1 or 4");
             c->spp = (int)value;

@@ -922,6 +922,7 @@ struct rtx_ctx {
     int sphere_bvh_depth = 0;
     int wf_blocks[3][4] = {};               // resident blocks of k_wf_trace / k_wf_shadow [STATS + 2 * WIDE], k_wf_shade [STATS]
     size_t wf_budget = (size_t)64 << 30;    // bytes the pipeline's arrays may take
+    bool wf_pool = true;                    // RTX_OPT_RAY_POOL
     unsigned char *d_frame = nullptr;
     size_t d_frame_bytes = 0;
     HostStage stage;                        // rtx_render's way to the caller's host buffer (RTX_OPT_PIN_OUTPUT)
@@ -1291,6 +1292,7 @@ using WfShadowKernel = void (*)(DevScene, WfArgs, Counters *);
 using WfShadeKernel = void (*)(DevScene, DevFrame, WfArgs, Counters *);
 const WfTraceKernel kWfTrace[4] = {k_wf_trace<false, false>, k_wf_trace<true, false>, k_wf_trace<false, true>, k_wf_trace<true, true>};
 const WfShadowKernel kWfShadow[4] = {k_wf_shadow<false, false>, k_wf_shadow<true, false>, k_wf_shadow<false, true>, k_wf_shadow<true, true>};
+const WfShadowKernel kWfShadowPool[2] = {k_wf_shadow_pool<false>, k_wf_shadow_pool<true>};
 const WfShadeKernel kWfShade[4] = {k_wf_shade<false, false>, k_wf_shade<true, false>, k_wf_shade<false, true>, k_wf_shade<true, true>};
 
 int wavefrontBlocks(rtx_ctx *c) {
@@ -1479,7 +1481,7 @@ int launchWavefront(rtx_ctx *c, const rtx_camera *cam, const rtx_frame *f, unsig
             hipLaunchKernelGGL(kWfTrace[variant], grid(c->wf_blocks[0][variant], samples << l), dim3(kBlock), lds, stream, s, dcam, fr, strip,
                                wfArgs(w, l, 0), c->d_counters);
             if (D == 0) break;
-            hipLaunchKernelGGL(kWfShadow[variant], grid(c->wf_blocks[1][variant], (samples << l) * (unsigned)std::max(1, s.n_lights)), dim3(kBlock), lds,
+            hipLaunchKernelGGL(s.sphere_bvh && c->wf_pool ? kWfShadowPool[variant & 1] : kWfShadow[variant], grid(c->wf_blocks[1][variant], (samples << l) * (unsigned)std::max(1, s.n_lights)), dim3(kBlock), lds,
                                stream, s, wfArgs(w, l, 1), c->d_counters);
             hipLaunchKernelGGL(kWfShade[variant], grid(c->wf_blocks[2][variant], samples << l), dim3(kBlock), 0, stream, s, fr,
                                wfArgs(w, l, 2), c->d_counters);
@@ -1599,6 +1601,7 @@ int rtx_set_option(rtx_ctx *c, int option, uint32_t value) {
             if (value > 2) return fail(RTX_E_INVALID, "RTX_OPT_QUAD_KERNEL: 0 never, 1 automatic, 2 whenever there are quad-mode tiles");
             c->quad_kernel = (int)value;
             break;
+        case RTX_OPT_RAY_POOL: c->wf_pool = value != 0; break;
         case RTX_OPT_TILE_PROBE:
             c->tile_probe = value != 0;
             c->sched_state.static_key.valid = false;

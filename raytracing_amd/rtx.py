@@ -17,7 +17,7 @@ HIP_FAST_LIB_PATH = os.path.join(_PKG, "librtx_hip_fast.so")  # the tolerance bu
 ASSETS_DIR = os.path.join(os.path.dirname(_PKG), "assets")
 
 MASK_SPHERES, MASK_CUBES, MASK_TRIANGLES, MASK_MODEL, MASK_ISLANDS, MASK_ALL = 1, 2, 4, 8, 16, 31
-OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID, OPT_BVH_BUILDER, OPT_SCHEDULE_FEEDBACK, OPT_QUAD, OPT_SPP, OPT_PIPELINE, OPT_PIPELINE_BUDGET_MB, OPT_PIN_OUTPUT, OPT_TILE_PROBE, OPT_QUAD_KERNEL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+OPT_STATS, OPT_PRUNE, OPT_FAR_CLIP, OPT_SURFACE_BIAS, OPT_MESH_GRID, OPT_BVH_BUILDER, OPT_SCHEDULE_FEEDBACK, OPT_QUAD, OPT_SPP, OPT_PIPELINE, OPT_PIPELINE_BUDGET_MB, OPT_PIN_OUTPUT, OPT_TILE_PROBE, OPT_QUAD_KERNEL, OPT_RAY_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 
 
 class RtxError(RuntimeError):

@@ -108,6 +108,43 @@ def test_four_samples_and_many_spheres(hip, oracle_backend, textures):
     assert np.array_equal(frames[0], frames[1])
 
 
+def test_shadow_rays_drawn_one_by_one_or_in_step(hip, oracle_backend, textures):
+    """RTX_OPT_RAY_POOL: with the spheres behind a tree, the lanes of a wave take their shadow rays from the list one
+    by one as they finish their walks (the default), or work through 64 of them in step.  Same frame as the oracle's
+    either way, same counts of rays and of lights found unhidden; also when the list ends in the middle of a wave
+    (a frame of a few tiles) and with one light or none."""
+    from raytracing_amd.rtx import OPT_RAY_POOL, OPT_STATS
+    ref = oracle_backend.create()
+    scenes.load_stress_scene(ref, oracle_backend, textures["water"], textures["map.jpg"], levels=1, n_spheres=3000)
+    ref.commit()
+    cam = hip.default_camera()
+    for w, h, d in ((160, 120, 4), (24, 16, 3), (9, 9, 2)):
+        want = ref.render(cam, w, h, d)
+        stats = []
+        for pool in (1, 0):
+            ctx = hip.create()
+            scenes.load_stress_scene(ctx, hip, textures["water"], textures["map.jpg"], levels=1, n_spheres=3000)
+            ctx.set_option(OPT_PIPELINE, 1), ctx.set_option(OPT_RAY_POOL, pool), ctx.set_option(OPT_STATS, 1)
+            ctx.commit()
+            f, st = ctx.render(cam, w, h, d, want_stats=True)
+            assert np.array_equal(f, want), (w, h, pool)
+            stats.append((st.primary_rays, st.secondary_rays, st.shadow_rays, st.sky_lookups, st.lit_lights))
+            ctx.set_option(OPT_STATS, 0)
+            assert np.array_equal(ctx.render(cam, w, h, d), want), (w, h, pool, "no statistics")
+        assert stats[0] == stats[1]
+    for lights in ([[0, 30, 10, 1.5]], []):
+        frames = []
+        for b in (oracle_backend, hip):
+            ctx = b.create()
+            scenes.load_stress_scene(ctx, b, textures["water"], textures["map.jpg"], levels=0, n_spheres=500)
+            ctx.set_lights(lights)
+            if b is hip:
+                ctx.set_option(OPT_PIPELINE, 1)
+            ctx.commit()
+            frames.append(ctx.render(b.default_camera(), 64, 48, 3))
+        assert np.array_equal(frames[0], frames[1]), len(lights)
+
+
 def test_strips_when_the_frame_exceeds_the_budget(hip, textures):
     """A frame larger than the pipeline's arrays is traced in strips of tiles; same bytes."""
     cam = hip.default_camera()
