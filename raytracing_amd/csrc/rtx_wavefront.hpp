@@ -366,12 +366,15 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_SHADOW_BLOCKS : 4
 // 4 samples): 43 instead of 31 lanes per vector instruction, a quarter fewer node trips, and the part around the
 // walks -- some thousand instructions a ray, now run 1.8 times as often -- two thirds dearer: 45.7 -> 41.8 ms per
 // frame for the shadow launches (threshold 16 / 28 / 40 / 52 lanes: frame 89.4 / 87.9 / 88.9 / 93.0 ms).
+#ifndef RTX_WF_POOL_BLOCKS
+#define RTX_WF_POOL_BLOCKS 5
+#endif
 #ifndef RTX_WF_POOL_LOW
 #define RTX_WF_POOL_LOW 28
 #endif
 constexpr unsigned kWfPoolLow = RTX_WF_POOL_LOW;
 template <bool STATS>
-__global__ __launch_bounds__(kBlock, STATS ? 2 : RTX_WF_SHADOW_BLOCKS) void k_wf_shadow_pool(DevScene s, WfArgs a, Counters *counters) {
+__global__ __launch_bounds__(kBlock, STATS ? 2 : RTX_WF_POOL_BLOCKS) void k_wf_shadow_pool(DevScene s, WfArgs a, Counters *counters) {
     __shared__ SmallScene q;
     __shared__ WfChunks ch;
     loadSmallScene(q, s);
