@@ -13,10 +13,11 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 #           kernel                        most scratch bytes per lane, most spilled VGPRs, most VGPRs
 LIMITS = {"k_render<false, false, false>": (512, 16, 168),  # three waves per SIMD; the frames of the recursion beyond the LDS slots live in scratch
           "k_render<false, false, true>": (640, 48, 168),   # the quad-mode launch beside it: must fit the same slots (its look-ahead hit record spills)
-          "k_wf_trace<false, false>": (64, 12, 128),  # the pipeline's walking kernels: four waves per SIMD ...
+          "k_wf_trace<false, false>": (0, 0, 128),   # the pipeline's walking kernels: four waves per SIMD ...
           "k_wf_shadow<false, false>": (0, 0, 128),
-          "k_wf_trace<false, true>": (192, 48, 96),   # ... and five in the general build (a stress-scene frame takes 4 % less
-          "k_wf_shadow<false, true>": (64, 16, 96),   # time with these spills and five waves than without them and four)
+          "k_wf_trace<false, true>": (112, 32, 96),   # ... and five in the general build (a stress-scene frame is faster with these
+          "k_wf_shadow<false, true>": (0, 0, 96),     # spills and five waves than without them and four; each spilled register is
+          "k_wf_shadow_pool<false>": (64, 16, 96),    # HBM-side traffic: at 40 and 34 spills the two hot ones moved a third of a frame's bytes)
           "k_wf_shade<false, false>": (0, 0, 128),
           "k_wf_shade<false, true>": (0, 0, 128)}
 
