@@ -132,17 +132,22 @@ def test_shadow_rays_drawn_one_by_one_or_in_step(hip, oracle_backend, textures):
             ctx.set_option(OPT_STATS, 0)
             assert np.array_equal(ctx.render(cam, w, h, d), want), (w, h, pool, "no statistics")
         assert stats[0] == stats[1]
-    for lights in ([[0, 30, 10, 1.5]], []):
+    rng = np.random.default_rng(5)
+    twenty = np.concatenate([rng.uniform(-40, 40, (20, 3)) + [0, 45, -40], rng.uniform(0.05, 0.4, (20, 1))], axis=1)
+    for lights, budget_mb in (([[0, 30, 10, 1.5]], 0), ([], 0), (twenty, 0), (twenty, 24), (None, 12)):
         frames = []
         for b in (oracle_backend, hip):
             ctx = b.create()
             scenes.load_stress_scene(ctx, b, textures["water"], textures["map.jpg"], levels=0, n_spheres=500)
-            ctx.set_lights(lights)
+            if lights is not None:
+                ctx.set_lights(lights)  # (twenty lights: five bits of a shadow request hold the light's number)
             if b is hip:
                 ctx.set_option(OPT_PIPELINE, 1)
+                if budget_mb:
+                    ctx.set_option(11, budget_mb)  # RTX_OPT_PIPELINE_BUDGET_MB: the frame in several strips
             ctx.commit()
-            frames.append(ctx.render(b.default_camera(), 64, 48, 3))
-        assert np.array_equal(frames[0], frames[1]), len(lights)
+            frames.append(ctx.render(b.default_camera(), 96, 72, 3))
+        assert np.array_equal(frames[0], frames[1]), (None if lights is None else len(lights), budget_mb)
 
 
 def test_strips_when_the_frame_exceeds_the_budget(hip, textures):
