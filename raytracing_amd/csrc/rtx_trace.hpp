@@ -82,25 +82,31 @@ RTX_DEV int walkPop(const int *stack, int stride, int &sp) {
     }
     return next;
 }
+template <bool WIDEN>
 RTX_DEV int walkStep(const BvhNode *nodes, int cur, float iax, float ibx, float iay, float iby, float iaz, float ibz, float ax, float bx,
                      float ay, float by, float az, float bz, float bound, int *stack, int stride, int &sp) {
-    const float4 *np = reinterpret_cast<const float4 *>(nodes + cur);
+    // (the node's address as the array's, which is the same in all lanes, plus 32 bits of offset: no address arithmetic
+    // in vector registers; trees stay below 4 GB)
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + ((unsigned)cur << 6));
+    static_assert(sizeof(BvhNode) == 64, "node offsets are index << 6");
     const float4 a = np[0], b = np[1], c = np[2];
     const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+    // t_far is widened by 2 ulp where the boxes themselves are all the margin there is (WIDEN)
+    constexpr float widen = WIDEN ? 1.0000004f : 1.0f;
     float tnL, tfL, tnR, tfR;
     {
         float t0 = __builtin_fmaf(a.x, iax, ax), t1 = __builtin_fmaf(a.w, ibx, bx);
         float t2 = __builtin_fmaf(a.y, iay, ay), t3 = __builtin_fmaf(b.x, iby, by);
         float t4 = __builtin_fmaf(a.z, iaz, az), t5 = __builtin_fmaf(b.y, ibz, bz);
         tnL = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-        tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+        tfL = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * widen;
     }
     {
         float t0 = __builtin_fmaf(b.z, iax, ax), t1 = __builtin_fmaf(c.y, ibx, bx);
         float t2 = __builtin_fmaf(b.w, iay, ay), t3 = __builtin_fmaf(c.z, iby, by);
         float t4 = __builtin_fmaf(c.x, iaz, az), t5 = __builtin_fmaf(c.w, ibz, bz);
         tnR = fmaxf(fmaxf(fminf(t0, t1), fminf(t2, t3)), fmaxf(fminf(t4, t5), 0.0f));
-        tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * 1.0000004f;
+        tfR = fminf(fminf(fmaxf(t0, t1), fmaxf(t2, t3)), fminf(fmaxf(t4, t5), bound)) * widen;
     }
     const bool hitL = tnL <= tfL, hitR = tnR <= tfR;
     // near child (or the only one hit) next, the far one onto the stack; written without nested branches: the
@@ -112,6 +118,28 @@ RTX_DEV int walkStep(const BvhNode *nodes, int cur, float iax, float ibx, float 
     int next = leftNext ? ch.x : ch.y;
     if (!(hitL || hitR)) next = walkPop(stack, stride, sp);
     return next;
+}
+
+// The inner loop of a walk that keeps its leaves: node steps; a leaf that is met goes into `pend` if that is free and
+// the walk goes on.  It ends, for all lanes of the wave together, when a lane that holds a leaf meets the next one or
+// no lane has an inner node left: the caller then tests the kept leaves.  (A loop of its own so that what the leaf
+// tests change -- the nearest hit, the bound -- is not carried around it: a dozen register moves a trip.)
+template <bool STATS, bool WIDEN>
+RTX_DEV void walkToLeaves(const BvhNode *nodes, float iax, float ibx, float iay, float iby, float iaz, float ibz, float ax, float bx, float ay,
+                          float by, float az, float bz, float bound, int &cur, int &sp, int &pend, int *stack, int stride,
+                          LaneCounters<STATS> &lc) {
+    for (;;) {
+        if (cur >= 0) {
+            RTX_COUNT(CNT_NODE_TESTS);
+            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
+            cur = walkStep<WIDEN>(nodes, cur, iax, ibx, iay, iby, iaz, ibz, ax, bx, ay, by, az, bz, bound, stack, stride, sp);
+        }
+        if (cur < 0 && cur != kWalkDone && pend == kWalkDone) {
+            pend = cur;
+            cur = walkPop(stack, stride, sp);
+        }
+        if (__ballot(cur < 0 && cur != kWalkDone) != 0ull || __ballot(cur >= 0) == 0ull) return;
+    }
 }
 
 // The triangle of leaf `leaf` of the mesh's tree against the ray: Triangle::rayIntersect and the bookkeeping of the
@@ -199,23 +227,17 @@ RTX_DEV bool meshIntersect(const DevScene &s, V3 orig, V3 dir, V3 inv, float &be
     const auto step = [&]() {
         RTX_COUNT(CNT_NODE_TESTS);
         if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-        cur = walkStep(s.bvh, cur, ix, ix, iy, iy, iz, iz, ox, ox, oy, oy, oz, oz, best_t, stack, stride, sp);
+        cur = walkStep<true>(s.bvh, cur, ix, ix, iy, iy, iz, iz, ox, ox, oy, oy, oz, oz, best_t, stack, stride, sp);
     };
     if constexpr (DEFER) {
         int pend = kWalkDone;
         for (;;) {
-            if (cur >= 0) step();
-            if (cur < 0 && cur != kWalkDone && pend == kWalkDone) {
-                pend = cur;
-                cur = walkPop(stack, stride, sp);
+            walkToLeaves<STATS, true>(s.bvh, ix, ix, iy, iy, iz, iz, ox, ox, oy, oy, oz, oz, best_t, cur, sp, pend, stack, stride, lc);
+            if (pend != kWalkDone) {
+                if (meshLeafTest<STATS>(s, orig, dir, inv, pend, best_t, best_tri, best_key, t_exit, lc)) return true;
+                pend = kWalkDone;
             }
-            if (__ballot(cur < 0 && cur != kWalkDone) != 0ull || __ballot(cur >= 0) == 0ull) {
-                if (pend != kWalkDone) {
-                    if (meshLeafTest<STATS>(s, orig, dir, inv, pend, best_t, best_tri, best_key, t_exit, lc)) return true;
-                    pend = kWalkDone;
-                }
-            }
-            if (cur == kWalkDone && pend == kWalkDone) break;
+            if (cur == kWalkDone) break;
         }
     } else {
         for (;;) {
@@ -280,29 +302,19 @@ RTX_DEV void sphereWalkSome(const DevScene &s, SphereWalker &w, V3 orig, V3 dir,
                             int stride, unsigned min_live, LaneCounters<STATS> &lc) {
     for (;;) {
         if ((unsigned)__popcll(__ballot(sphereWalkerLive(w))) < min_live) return;
-        if (w.cur >= 0) {
-            RTX_COUNT(CNT_NODE_TESTS);
-            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            w.cur = walkStep(s.sphere_bvh, w.cur, w.iax, w.ibx, w.iay, w.iby, w.iaz, w.ibz, w.ax, w.bx, w.ay, w.by, w.az, w.bz, w.bound, stack,
-                             stride, w.sp);
-        }
-        if (w.cur < 0 && w.cur != kWalkDone && w.pend == kWalkDone) {
-            w.pend = w.cur;
-            w.cur = walkPop(stack, stride, w.sp);
-        }
-        if (__ballot(w.cur < 0 && w.cur != kWalkDone) != 0ull || __ballot(w.cur >= 0) == 0ull) {
-            if (w.pend != kWalkDone) {
-                const int i = ~w.pend;
-                w.pend = kWalkDone;
-                const float4 sph = s.spheres[i];
-                RTX_COUNT(CNT_SPHERE_TESTS);
-                float curDist = 0.0f;
-                if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
-                    minDist = curDist;
-                    index = i;
-                    if (curDist < t_exit) w.cur = kWalkDone, w.sp = 0;
-                    w.bound = fminf(w.reach, 1.01f * (minDist + s.sphere_rmax));
-                }
+        walkToLeaves<STATS, false>(s.sphere_bvh, w.iax, w.ibx, w.iay, w.iby, w.iaz, w.ibz, w.ax, w.bx, w.ay, w.by, w.az, w.bz, w.bound, w.cur, w.sp, w.pend,
+                            stack, stride, lc);
+        if (w.pend != kWalkDone) {
+            const int i = ~w.pend;
+            w.pend = kWalkDone;
+            const float4 sph = s.spheres[i];
+            RTX_COUNT(CNT_SPHERE_TESTS);
+            float curDist = 0.0f;
+            if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
+                minDist = curDist;
+                index = i;
+                if (curDist < t_exit) w.cur = kWalkDone, w.sp = 0;
+                w.bound = fminf(w.reach, 1.01f * (minDist + s.sphere_rmax));
             }
         }
     }
@@ -344,35 +356,25 @@ RTX_DEV void sphereWalk(const DevScene &s, V3 orig, V3 dir, V3 inv, float reach,
                         int *stack, int stride, LaneCounters<STATS> &lc) {
     SphereWalker w = sphereWalkerStart(s, orig, dir, inv, reach, minDist);
     for (;;) {
-        if (w.cur >= 0) {
-            RTX_COUNT(CNT_NODE_TESTS);
-            if constexpr (STATS) lc.v[CNT_NODE_TRIPS] += firstActiveLane() ? 1u : 0u;
-            w.cur = walkStep(s.sphere_bvh, w.cur, w.iax, w.ibx, w.iay, w.iby, w.iaz, w.ibz, w.ax, w.bx, w.ay, w.by, w.az, w.bz, w.bound, stack,
-                             stride, w.sp);
-        }
         // A lane that comes upon a leaf keeps it for later and walks on.  The kept spheres are tested, by all lanes
         // that hold one, when a lane holds one and comes upon the next, or when no lane has an inner node left: the
         // sphere test then runs for some twenty lanes instead of eight per trip, and the lanes that used to wait for
         // it walk (10 000 spheres: 116.6 -> 104.2 ms a frame).  The result is the nearest hit, the lowest index among
         // equals, whatever the order of the tests; a test made later only lets the walk look at boxes that an earlier
         // hit would have culled.
-        if (w.cur < 0 && w.cur != kWalkDone && w.pend == kWalkDone) {
-            w.pend = w.cur;
-            w.cur = walkPop(stack, stride, w.sp);
-        }
-        if (__ballot(w.cur < 0 && w.cur != kWalkDone) != 0ull || __ballot(w.cur >= 0) == 0ull) {
-            if (w.pend != kWalkDone) {
-                const int i = ~w.pend;
-                w.pend = kWalkDone;
-                const float4 sph = s.spheres[i];
-                RTX_COUNT(CNT_SPHERE_TESTS);
-                float curDist = 0.0f;
-                if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
-                    minDist = curDist;
-                    index = i;
-                    if (curDist < t_exit) return;
-                    w.bound = fminf(w.reach, 1.01f * (minDist + s.sphere_rmax));
-                }
+        walkToLeaves<STATS, false>(s.sphere_bvh, w.iax, w.ibx, w.iay, w.iby, w.iaz, w.ibz, w.ax, w.bx, w.ay, w.by, w.az, w.bz, w.bound, w.cur, w.sp, w.pend,
+                            stack, stride, lc);
+        if (w.pend != kWalkDone) {
+            const int i = ~w.pend;
+            w.pend = kWalkDone;
+            const float4 sph = s.spheres[i];
+            RTX_COUNT(CNT_SPHERE_TESTS);
+            float curDist = 0.0f;
+            if (sphereHit(v3(sph.x, sph.y, sph.z), sph.w, orig, dir, curDist) && (curDist < minDist || (curDist == minDist && i < index))) {
+                minDist = curDist;
+                index = i;
+                if (curDist < t_exit) return;
+                w.bound = fminf(w.reach, 1.01f * (minDist + s.sphere_rmax));
             }
         }
         if (!sphereWalkerLive(w)) return;
