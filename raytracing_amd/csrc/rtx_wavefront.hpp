@@ -12,7 +12,8 @@
 //                Hit: a node record (point, normal, view, material) is appended to the level's node list
 //                and one shadow request per light that can contribute (aimLight) to the shadow lists.
 //   k_wf_shadow  one lane per shadow request: the shadow ray of calcLightning (:65-72); sets the light's
-//                bit in the node's `hidden` mask.
+//                bit in the node's `hidden` mask.  (k_wf_shadow_pool, for scenes whose spheres sit behind a
+//                tree: the same, with the lanes of a wave drawing on the list one by one as they finish.)
 //   k_wf_shade   one lane per node: adds up the lights in the reference's order (:73-78), forms the
 //                node's own colour, and appends the reflect / refract rays (:95-101) to the next level's
 //                request lists.  Nodes of the last level take their children's sky colours in place.
