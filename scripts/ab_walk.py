@@ -27,7 +27,7 @@ for wl in names.split(","):
             if stats:
                 ctx.set_option(rtx.OPT_STATS, 1)
             for pair in filter(None, os.environ.get("RTX_AB_OPTS", "").split(",")):  # id=value pairs of rtx_set_option
-                ctx.set_option(int(pair.split("=")[0]), float(pair.split("=")[1]))
+                ctx.set_option(int(pair.split("=")[0]), int(pair.split("=")[1]))
             ctx.commit()
             return ctx
         ctx = make(False)
