@@ -1317,6 +1317,8 @@ int wavefrontBlocks(rtx_ctx *c) {
     return RTX_OK;
 }
 
+constexpr size_t kWfThinBytes = 3 * sizeof(float4) + sizeof(uint2);  // a thin record: own, kid0, kid1, meta
+
 // bits that hold a light's number in a shadow request
 unsigned wfLightBits(int n_lights) {
     unsigned bits = 1;
@@ -1342,7 +1344,7 @@ WfPlan wavefrontPlan(int D, int n_lights, size_t strip) {
             p.req_cap[l + 1] = (unsigned)req_cap;
             if (kWfSub * req_cap >= (size_t)kWfMaxIndex) p.fits = false;
             // requests (the two classes of a sub-list share its region), thin records
-            bytes += kWfSub * req_cap * 2 * sizeof(float4) + kWfSub * node_cap * 3 * sizeof(float4) + 1024;
+            bytes += kWfSub * req_cap * 2 * sizeof(float4) + kWfSub * node_cap * kWfThinBytes + 1024;
             req_chunks = (size_t)kWfSub * (req_cap / kWfChunk) + kWfMaxLists;  // all entries in whole chunks + a partly filled one per sub-list
         }
     }
@@ -1411,7 +1413,7 @@ int wavefrontBuffers(rtx_ctx *c, int D, size_t frame_samples, int spp) {
         if (l + 1 < D) {
             w.ray_o[l + 1] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.req_cap[l + 1] * sizeof(float4)));
             w.ray_d[l + 1] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.req_cap[l + 1] * sizeof(float4)));
-            w.thin[l] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.node_cap[l] * 3 * sizeof(float4)));
+            w.thin[l] = reinterpret_cast<float4 *>(take((size_t)kWfSub * plan.node_cap[l] * kWfThinBytes));
         }
     }
     if (D > 0) {
@@ -1438,6 +1440,7 @@ WfArgs wfArgs(const WfMem &w, int l, int launch) {
     a.work = w.counters->work[launch][l];
     a.ray_o = w.ray_o[l], a.ray_d = w.ray_d[l], a.next_o = w.ray_o[l + 1], a.next_d = w.ray_d[l + 1];
     a.pt = w.pt, a.nrm = w.nrm, a.vw = w.vw, a.dif = w.dif, a.hidden = w.hidden, a.shadow_q = w.shadow_q, a.thin = w.thin[l], a.parent = l == 0 ? w.samples : w.thin[l - 1];
+    a.thin_n = kWfSub * w.plan.node_cap[l], a.parent_n = l == 0 ? 0u : kWfSub * w.plan.node_cap[l - 1];
     a.level = l;
     a.light_bits = wfLightBits(w.n_lights);
     return a;

@@ -79,9 +79,10 @@ struct WfStrip {
 //        pt  point.xyz, material index   nrm  N.xyz, cast mask
 //        vw  view.xyz                    dif  diffuse.rgb (after water / island override), link to the parent
 //        hidden  one word: the lights found hidden (k_wf_shadow ORs into it; a cache line holds 32 nodes' words)
-//   thin (3 x float4, one array per level, lives until the level is resolved):
-//        [0] own colour.rgb, a2          [1] reflect child's colour.rgb, a3
-//        [2] refract child's colour.rgb, link to the parent | kHasRefl | kHasRefr
+//   thin (lives until the level is resolved; per level four arrays in one block of thin_n records each: what a launch
+//        does not need it does not fetch, and a child's colour is one whole 16-byte store):
+//        own   own colour.rgb, a2                  kid0  reflect child's colour.rgb (written by the child)
+//        meta  a3, link to the parent | kHasRefl | kHasRefr (8 bytes)   kid1  refract child's colour.rgb
 struct WfArgs {
     WfList req, nodes, shadows, next_req;  // this level's requests, nodes, shadow requests; the next level's requests
     unsigned *work;                        // this launch's chunk hand-out counters
@@ -90,8 +91,9 @@ struct WfArgs {
     float4 *pt, *nrm, *vw, *dif;
     unsigned *hidden;
     unsigned *shadow_q;
-    float4 *thin;                          // this level's thin records
+    float4 *thin;                          // this level's thin records: own at [0, thin_n), kid0 and kid1 after it, then meta
     float4 *parent;                        // the level above's thin records, or the strip's sample colours (level 0)
+    unsigned thin_n, parent_n;             // records per array of the two
     int level;
     unsigned light_bits;                   // bits of a shadow request that hold the light's number (as many as the scene's lights need)
 };
@@ -100,14 +102,12 @@ RTX_DEV unsigned laneId() { return __builtin_amdgcn_mbcnt_hi(0xffffffffu, __buil
 RTX_DEV unsigned lanesBelow(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
 // the colour of a finished traceRay call goes where its caller reads it
-RTX_DEV void wfDeliver(float4 *parent, int level, unsigned link, V3 c) {
-    if (level == 0) {
-        parent[link & kLinkIndex] = make_float4(c.x, c.y, c.z, 0.0f);
-    } else {
-        float *p = reinterpret_cast<float *>(parent + 3 * (size_t)(link & kLinkIndex) + ((link & kLinkRefr) ? 2 : 1));
-        p[0] = c.x, p[1] = c.y, p[2] = c.z;  // (the fourth word of either record is not the child's to write)
-    }
+RTX_DEV void wfDeliver(float4 *parent, unsigned parent_n, int level, unsigned link, V3 c) {
+    // level 0: the sample's colour; below: the parent's kid0 (reflect) or kid1 (refract) entry
+    const size_t at = level == 0 ? 0 : (size_t)parent_n * ((link & kLinkRefr) ? 2u : 1u);
+    parent[at + (link & kLinkIndex)] = make_float4(c.x, c.y, c.z, 0.0f);
 }
+RTX_DEV uint2 *wfThinMeta(float4 *thin, unsigned thin_n) { return reinterpret_cast<uint2 *>(thin + 3 * (size_t)thin_n); }
 
 // does the ray pass the (slightly widened) box around the mesh?  Only decides which list a request goes to.
 RTX_DEV bool wfMeshClass(const DevScene &s, V3 orig, V3 dir) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kBlock, STATS ? 2 : WIDE ? RTX_WF_TRACE_BLOCKS : 4)
         if (casts) hit = sceneIntersect<STATS, WIDE, true>(s, q, orig, dir, false, -1.0f, h, md, stack, kBlock, lc);
         if (valid && !hit) {
             RTX_COUNT(CNT_SKY);
-            wfDeliver(a.parent, level, link, skyColor(s, dir));
+            wfDeliver(a.parent, a.parent_n, level, link, skyColor(s, dir));
         }
         // ---- a node per hit; a shadow request per light that can contribute, classed by its ray ----
         const bool node_here = valid && hit;
@@ -529,13 +529,12 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(DevScene s, DevFrame fr, Wf
                     RTX_COUNT(CNT_SKY);
                     c = c + skyColor(s, refrD) * m.a3;
                 }
-                wfDeliver(a.parent, level, link, c);
+                wfDeliver(a.parent, a.parent_n, level, link, c);
                 doRefl = doRefr = false;
             } else {
-                float4 *t = a.thin + 3 * (size_t)i;
-                t[0] = make_float4(base.x, base.y, base.z, m.a2);
-                t[1] = make_float4(0.0f, 0.0f, 0.0f, m.a3);
-                t[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((link & (kLinkIndex | kLinkRefr)) | (doRefl ? kHasRefl : 0u) | (doRefr ? kHasRefr : 0u)));
+                a.thin[i] = make_float4(base.x, base.y, base.z, m.a2);
+                wfThinMeta(a.thin, a.thin_n)[i] =
+                    make_uint2(__float_as_uint(m.a3), (link & (kLinkIndex | kLinkRefr)) | (doRefl ? kHasRefl : 0u) | (doRefr ? kHasRefr : 0u));
             }
         }
         // the children's requests, classed by their rays
@@ -564,13 +563,19 @@ __global__ __launch_bounds__(kBlock) void k_wf_resolve(WfArgs a) {
     for (unsigned chunk = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * (kBlock / 64u)) {
         unsigned i;
         if (!wfChunkEntry(ch, a.nodes, chunk, i)) continue;
-        const float4 *t = a.thin + 3 * (size_t)i;
-        const float4 t0 = t[0], t1 = t[1], t2 = t[2];
-        const unsigned link = __float_as_uint(t2.w);
-        V3 c = v3(t0.x, t0.y, t0.z);
-        if (link & kHasRefl) c = c + v3(t1.x, t1.y, t1.z) * t0.w;
-        if (link & kHasRefr) c = c + v3(t2.x, t2.y, t2.z) * t1.w;
-        wfDeliver(a.parent, level, link, c);
+        const float4 own = a.thin[i];
+        const uint2 meta = wfThinMeta(a.thin, a.thin_n)[i];
+        const unsigned link = meta.y;
+        V3 c = v3(own.x, own.y, own.z);
+        if (link & kHasRefl) {
+            const float4 kid = a.thin[(size_t)a.thin_n + i];
+            c = c + v3(kid.x, kid.y, kid.z) * own.w;
+        }
+        if (link & kHasRefr) {
+            const float4 kid = a.thin[2 * (size_t)a.thin_n + i];
+            c = c + v3(kid.x, kid.y, kid.z) * __uint_as_float(meta.x);
+        }
+        wfDeliver(a.parent, a.parent_n, level, link, c);
     }
 }
 
