@@ -588,7 +588,7 @@ def main():
         scene_bytes = scene_resident_bytes(stress, textures)
         compulsory = rows * WIDTH * 3 + scene_bytes
         roofline = {
-            "bound": "valu", "kernel": "k_wf_trace + k_wf_shadow + k_wf_shade<.., true> (level-by-level pipeline, all launches of a frame)" if stress else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+            "bound": "valu", "kernel": "k_wf_trace + k_wf_shadow(_pool) + k_wf_shade<.., true> (level-by-level pipeline, all launches of a frame)" if stress else "k_render<false, false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 5), "traffic": traffic,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
             "note": "FP32 vector (not MFMA: no dense contraction). Pixel arithmetic is unfused and unpacked to track "
